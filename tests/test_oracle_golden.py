@@ -1,0 +1,308 @@
+"""Pins the CPU oracle on every known-answer test the reference holds for the hot path.
+
+Mirrors tests/basic-cases.rs, tests/mismatch.rs and the #[cfg(test)] blocks of src/align.rs,
+src/filter/align.rs, src/utils.rs and src/reference_library.rs of the reference.  CPU only.
+"""
+import json
+import os
+
+import pytest
+
+from oracle import oracle as ora
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EXPECTED = json.load(open(os.path.join(GOLDEN, "expected.json")))
+SEP = "§"
+
+
+def read_fastq(path):
+    """bio::io::fastq-like reader for the tiny fixtures: returns (names, sequences)."""
+    lines = open(path).read().split("\n")
+    names, seqs = [], []
+    i = 0
+    while i < len(lines):
+        if not lines[i]:
+            i += 1
+            continue
+        assert lines[i].startswith("@"), "Unable to read sequence"
+        names.append(lines[i][1:])
+        seqs.append(lines[i + 1])
+        assert lines[i + 2].startswith("+")
+        # the quality line may be glued to the next header in basic.fastq (no trailing newline issue)
+        i += 4
+    return names, seqs
+
+
+def load_case_data(library, reads, strand_filter):
+    # tests/utils.rs:17-61 get_data
+    cfg, ref = ora.get_reference_library(os.path.join(GOLDEN, "libraries", library), strand_filter)
+    index = ora.Index.from_reference(ref)
+    names, seqs = read_fastq(os.path.join(GOLDEN, "reads", reads))
+    return cfg, ref, index, names, seqs
+
+
+@pytest.mark.parametrize("case", EXPECTED["get_calls"], ids=lambda c: c["name"])
+def test_get_calls_known_answers(case):
+    cfg, ref, index, _, seqs = load_case_data(case["library"], case["reads"], case["strand_filter"])
+    cfg = cfg.copy(num_mismatches=case["num_mismatches"])
+    if "group_column" in case:
+        # tests/basic-cases.rs:15-40 get_group_by_data
+        col = ref.push_column("test_group_on", case["group_column"])
+        assert col == 4
+        ref.group_on = 4
+    res = ora.get_calls_fastq(index, ref, cfg, seqs)
+    assert [[f, c] for f, c in res.rows] == case["rows"]
+    # the multi-threaded (hash-partitioned) CPU-S variant must give the same table
+    res4 = ora.get_calls_fastq(index, ref, cfg, seqs, n_threads=4)
+    assert res4.rows == res.rows
+
+
+def _unit_cfg(d):
+    c = ora.Config()
+    for k, v in d.items():
+        if k == "strand_filter":
+            v = ora.CHEM[v]
+        setattr(c, k, int(v) if isinstance(v, bool) else v)
+    return c
+
+
+@pytest.mark.parametrize("case", EXPECTED["pseudoalign_unit"]["cases"], ids=lambda c: c["name"])
+def test_pseudoalign_unit(case):
+    # src/align.rs:997-1107
+    u = EXPECTED["pseudoalign_unit"]
+    index = ora.Index.from_sequences(u["index_sequences"])
+    cfg = _unit_cfg(u["config"])
+    if "score_threshold" in case:
+        cfg.score_threshold = case["score_threshold"]
+    score, filt = index.pseudoalign(case["read"], cfg, u["min_read_length"])
+    if case.get("score") is not None:
+        assert score == (case["score"][0], case["score"][1], case["score"][2])
+    if case["filter"] is None:
+        assert filt is None
+    else:
+        assert filt == tuple(case["filter"])
+
+
+def test_per_read_hand_derived_values():
+    # coverage / mismatch values per read, per mismatch budget
+    for lib, reads_file in (("basic.json", "basic.fastq"), ("mismatch.json", "mismatch.fastq")):
+        cfg, ref, index, names, seqs = load_case_data(lib, reads_file, "none")
+        rows = ref.column(ref.sequence_name_idx)
+        for name, per_nm in EXPECTED["per_read_hand_derived"][lib].items():
+            seq = seqs[names.index(name)]
+            for nm, exp in per_nm.items():
+                got = index.map_read(seq, int(nm))
+                if exp is None:
+                    assert got is None
+                    continue
+                cls, cov, mm = got
+                assert [rows[i] for i in cls] == exp[0], (lib, name, nm)
+                assert (cov, mm) == (exp[1], exp[2]), (lib, name, nm)
+
+
+def test_basic_graph_shape():
+    # basic.json gives 16 unitigs; forward A02 side lengths 32,42,59x4,104
+    _, ref, index, _, _ = load_case_data("basic.json", "basic.fastq", "none")
+    st = index.stats()
+    assert st["nodes"] == 16
+    rows = ref.column(ref.sequence_name_idx)
+    fwd = []
+    for n in range(st["nodes"]):
+        seq, colour, _, _ = index.node(n)
+        names = [rows[i] for i in index.eq_class(colour)]
+        if all(x.startswith("A02") and not x.endswith("rev") for x in names):
+            fwd.append(len(seq))
+    assert sorted(fwd) == [32, 42, 59, 59, 59, 59, 104]
+
+
+def test_lowercase_and_non_acgt_bases():
+    # a12: lower-case accepted; anything else behaves as 'A'
+    index = ora.Index.from_sequences(["ACGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCA"])
+    a = index.map_read("ACGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCA", 0)
+    b = index.map_read("acgttgcaaggcttaaccggttaacgtagctagctaggatcca", 0)
+    c = index.map_read("NCGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCN", 0)  # N -> A at both ends
+    assert a == b == c == ([0], 43, 0)
+
+
+# ---------------- filter/align.rs:47-195 ----------------
+@pytest.mark.parametrize("args,exp_score,exp_filter", [
+    (([1, 2], 50, 1.0, 20, 0.5, False, 0, 0), ([1, 2], 1.0, 50), None),
+    (([1, 2], 10, 0.10, 20, 0.5, False, 0, 0), None, ("ScoreBelowThreshold", 0.10, 10)),
+    (([1, 2], 50, 1.0, 20, 0.5, True, 0, 0), None, ("DiscardedMultipleMatch", 1.0, 50)),
+    (([1, 2], 50, 1.0, 20, 0.5, False, 1, 0), ([1, 2], 1.0, 50), None),
+    (([1, 2], 50, 1.0, 20, 0.5, False, 1, 1), ([1, 2], 1.0, 50), None),
+    (([1, 2], 50, 1.0, 20, 0.5, False, 1, 2), None, ("AboveMismatchThreshold", 1.0, 50)),
+])
+def test_filter_alignment_by_metrics(args, exp_score, exp_filter):
+    score, filt = ora.filter_alignment_by_metrics(*args)
+    assert score == exp_score
+    assert filt == exp_filter
+
+
+# ---------------- align.rs:1109-1143 filter_pair ----------------
+def test_filter_pair():
+    assert ora.filter_pair([], []) is True
+    assert ora.filter_pair([1, 2, 3], []) is True
+    assert ora.filter_pair([], [1, 2, 3]) is True
+    assert ora.filter_pair([1, 2, 3], [4, 5, 6]) is True
+    assert ora.filter_pair([1, 2, 3], [1, 2, 3]) is False
+    assert ora.filter_pair([1, 2, 3, 4], [1, 2, 3]) is True
+
+
+# ---------------- align.rs:1029-1059 fixtures + :1145-1231 ----------------
+def unit_reference(group_on=0, col1=None):
+    return ora.Reference.raw(["nt_sequence", "gene"],
+                             [["seq1", "seq2", "seq3"], col1 or ["geneA", "geneB", "geneA"]], group_on, 0, 0)
+
+
+def unit_config(**kw):
+    c = _unit_cfg(EXPECTED["pseudoalign_unit"]["config"])
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_process_equivalence_class_to_feature_list():
+    f = ora.process_equivalence_class_to_feature_list
+    assert f([0, 1, 2], unit_reference(), unit_config(), False) == ["seq1", "seq2", "seq3"]
+    assert f([0, 1, 2], unit_reference(1), unit_config(), False) == ["geneA", "geneB"]
+    assert f([0, 1, 2], unit_reference(1, ["geneA", "", "geneA"]), unit_config(), False) == ["geneA", "seq2"]
+    assert f([0, 1, 2], unit_reference(1, ["geneA", "", "geneA"]), unit_config(), True) == ["seq1", "seq2", "seq3"]
+    assert f([0, 1, 2], unit_reference(), unit_config(discard_multi_hits=1), False) == []
+    assert f([], unit_reference(), unit_config(), False) == []
+    assert f([2, 0, 1], unit_reference(1), unit_config(), False) == ["geneA", "geneB"]
+
+
+def rv(name):
+    return name + SEP + "rev"
+
+
+# ---------------- align.rs:1339-1452 ----------------
+def test_filter_orientation_on_library_chemistry():
+    f = ora.filter_orientation_on_library_chemistry
+    assert f(["feat1", rv("feat2")], ["feat3", rv("feat4")], "none") == (["feat1", "feat2"], ["feat3", "feat4"])
+    assert f(["feat1", "feat2", rv("feat4"), "feat5"], ["feat1", "feat3", "feat4", rv("feat5")], "unstranded") == (
+        ["feat2", "feat4", "feat5"], ["feat3", "feat4", "feat5"])
+    assert f(["feat1", rv("feat2"), "feat3", "feat5", "feat6", rv("feat8")],
+             ["feat1", "feat3", "feat8", "feat4", rv("feat5"), rv("feat7")], "fiveprime") == (
+        ["feat5", "feat6"], ["feat5", "feat7"])
+    assert f(["feat1", rv("feat2"), "feat3", rv("feat5")],
+             ["feat7", "feat1", "feat5", rv("feat6"), rv("feat4")], "threeprime") == (
+        ["feat2", "feat5"], ["feat7", "feat5"])
+
+
+# ---------------- align.rs:1254-1337 (through the public entry with explicit rev markers) ----------------
+def test_filter_stranded_literals():
+    f = ora.filter_orientation_on_library_chemistry
+    # test_filter_five_prime
+    seq = ["feat1", rv("feat2"), "feat4", rv("feat5"), "feat6"]
+    mate = ["feat1", rv("feat3"), rv("feat4"), "feat5", "feat7"]
+    assert f(seq, mate, "fiveprime") == (["feat4", "feat6"], ["feat3", "feat4"])
+    # test_filter_three_prime
+    seq = ["feat1", rv("feat2"), "feat4", rv("feat5"), "feat6"]
+    mate = ["feat1", "feat3", rv("feat4"), "feat5", rv("feat7")]
+    assert f(seq, mate, "threeprime") == (["feat2", "feat5"], ["feat3", "feat5"])
+    # test_filter_unstranded
+    seq = ["feat1", rv("feat2"), rv("feat4"), rv("feat5")]
+    mate = ["feat1", "feat3", "feat4", rv("feat5")]
+    assert f(seq, mate, "unstranded") == (["feat2", "feat4"], ["feat3", "feat4"])
+
+
+# ---------------- align.rs:1454-1530 ----------------
+def test_filter_read_calls_with_orientation():
+    f = ora.filter_read_calls_with_orientation
+    assert f(["name1", "name2", "name3", "name4"]) == ["name1", "name2", "name3", "name4"]
+    assert f(["name1", rv("name1"), "name2", rv("name3"), "name3", rv("name4")]) == ["name2", rv("name4")]
+    allrev = [rv("name1"), rv("name2"), rv("name3"), rv("name4")]
+    assert f(allrev) == allrev
+    mixed = ["name1", rv("name2"), rv("name1"), "name3", rv("name4"), rv("name3"), "name5", rv("name6"), "name7",
+             rv("name8"), "name9", "name8"]
+    assert f(mixed) == [rv("name2"), rv("name4"), "name5", rv("name6"), "name7", "name9"]
+
+
+# ---------------- align.rs:1610-1654 through coerce ----------------
+def test_intersect_levels_through_coerce():
+    names = ["1", "2", "3", "4", "5", "6"]
+    ref = ora.Reference.raw(["sequence_name"], [names], 0, 0, 0)
+    cfg = unit_config(strand_filter=ora.CHEM["none"], max_hits_to_report=10)
+    cfg.intersect_level = 0
+    assert ora.coerce(ref, cfg, [0, 1, 2], [3, 4, 5]) == (names, "None")
+    cfg.intersect_level = 2
+    assert ora.coerce(ref, cfg, [0, 1, 2, 3], [3, 4, 5]) == (["4"], "None")
+    cfg.intersect_level = 1
+    assert ora.coerce(ref, cfg, [0, 1, 2], [3, 4, 5]) == (names, "None")
+    cfg.intersect_level = 2
+    assert ora.coerce(ref, cfg, [0, 1, 2], [3, 4, 5]) == ([], "TriageEmptyEquivalenceClass")
+    cfg.intersect_level = 0
+    cfg.max_hits_to_report = 5
+    assert ora.coerce(ref, cfg, [0, 1, 2], [3, 4, 5]) == ([], "MaxHitsExceeded")
+
+
+# ---------------- utils.rs:362-403 ----------------
+def test_shannon_entropy():
+    assert abs(ora.shannon_entropy("A") - 0.0) < 1e-10
+    assert abs(ora.shannon_entropy("AT") - 1.0) < 1e-10
+    assert abs(ora.shannon_entropy("ATCG") - 2.0) < 1e-10
+    import math
+    assert abs(ora.shannon_entropy("AAAT") + (0.75 * math.log2(0.75) + 0.25 * math.log2(0.25))) < 1e-10
+    assert abs(ora.shannon_entropy("ATCGATCGATCG") - 2.0) < 1e-10
+
+
+# ---------------- utils.rs:162-217 ----------------
+def test_revcomp():
+    assert ora.revcomp("ATGC") == "GCAT"
+    assert ora.revcomp("CCGGTTAA") == "TTAACCGG"
+    assert ora.revcomp("acgtuUNn") == "NNAaacgt"
+    with pytest.raises(ora.OracleError, match="Input sequence base is not DNA"):
+        ora.revcomp("ATGX")
+
+
+# ---------------- align.rs:1656-1752 ----------------
+def adjust_quality(q):
+    return "".join(chr(ord(c) - 33) for c in q)
+
+
+def test_maxinfo():
+    assert ora.maxinfo(adjust_quality("I" * 20), 15, 0.5) == 20
+    assert ora.maxinfo(adjust_quality("!" * 20), 15, 0.9) == 1
+    assert ora.maxinfo(adjust_quality("IIIIII!!!!!!IIIIII"), 15, 0.7) == 6
+    assert ora.maxinfo(adjust_quality("I" * 20), 15, 1.0) == 20
+    assert ora.maxinfo(adjust_quality("I" * 20), 15, 0.0) == 20
+    # trim_sequence literals: strictness 0.9 all-low -> 1 base kept; 0.8 mixed -> 6
+    assert ora.maxinfo(adjust_quality("IIIIII!!!!!!IIIIII"), 15, 0.8) == 6
+
+
+# ---------------- reference_library.rs:301-480 ----------------
+def test_reference_library_valid_json():
+    cfg, ref = ora.get_reference_library(os.path.join(GOLDEN, "libraries", "reference-library-correct.json"), "none")
+    assert cfg.score_percent == 0.85 and cfg.score_filter == 200 and cfg.score_threshold == 300
+    assert cfg.num_mismatches == 2 and cfg.discard_multiple_matches == 1 and cfg.require_valid_pair == 0
+    assert cfg.discard_multi_hits == 1 and cfg.intersect_level == 1 and cfg.max_hits_to_report == 10
+    assert cfg.trim_target_length == 40 and cfg.trim_strictness == 0.9
+    assert ref.group_on == 1
+    assert ref.headers == ["id", "feature_id", "sequence_name", "sequence"]
+    assert ref.column(0) == ["1", "1", "2", "2"]
+    assert ref.column(1) == ["fid1", "fid1", "fid2", "fid2"]
+    assert ref.column(2) == ["seq_name1", "seq_name1" + SEP + "rev", "seq_name2", "seq_name2" + SEP + "rev"]
+    assert ref.column(3) == ["ATGC", "GCAT", "CGTA", "TACG"]
+    assert ref.sequence_name_idx == 2 and ref.sequence_idx == 3
+
+
+@pytest.mark.parametrize("lib,exp", [
+    ("reference-library-rna.json", ["ATGCTT", "AAGCAT", "tTgcAT", "ATgcAa"]),
+    ("reference-library-mixed-case-rna.json", ["atGcTt", "aAgCat", "TtgCAt", "aTGcaA"]),
+    ("reference-library-no-rna-bases.json", ["ATGCGT", "ACGCAT", "CGTACG", "CGTACG"]),
+])
+def test_reference_library_rna_conversion(lib, exp):
+    _, ref = ora.get_reference_library(os.path.join(GOLDEN, "libraries", lib), "none")
+    assert ref.column(3) == exp
+
+
+def test_natural_lexical_cmp():
+    c = ora.natural_lexical_cmp
+    assert c("A02-0", "A02-LC") < 0
+    assert c("a2", "A10") < 0            # numbers by value, case-insensitive
+    assert c("F00012-3", "F00012-10") < 0
+    assert c("b", "B") > 0 and c("B", "b") < 0  # tie on the lexical form -> plain order
+    assert c("x", "x") == 0
+    assert c("A02-0", "A02-0" + SEP + "rev") < 0
