@@ -1,0 +1,151 @@
+/* nimble_hip.h -- C ABI of the MI355X (gfx950) device path of nimble-aligner's hot path.
+ *
+ * This is the boundary a maintainer of BimberLab/nimble-aligner binds from Rust (see
+ * INTEGRATION.md for the `extern "C"` block).  The reference has no FFI of its own: the
+ * hot path sits behind the in-process seam `score::call` (src/score.rs:14-31) plus index
+ * construction `debruijn_mapping::build_index::<Kmer30>` (src/bin/main.rs:121-128).  Each
+ * entry point below names the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative NIMBLE_E_* code, with text from nimble_last_error(); nothing throws across
+ * the ABI.  There is no CPU fallback: without a HIP device every device entry point fails
+ * with NIMBLE_E_NO_DEVICE.
+ */
+#ifndef NIMBLE_HIP_H
+#define NIMBLE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIMBLE_ABI_VERSION 1
+
+enum {
+  NIMBLE_OK = 0,
+  NIMBLE_E_INVALID = -1,   /* bad argument */
+  NIMBLE_E_NO_DEVICE = -2, /* no HIP device / HIP runtime error at init */
+  NIMBLE_E_HIP = -3,       /* HIP runtime error */
+  NIMBLE_E_NOMEM = -4,
+  NIMBLE_E_OVERFLOW = -5,  /* a device pool overflowed even after growth */
+  NIMBLE_E_INTERNAL = -6
+};
+
+/* FilterReason codes, same order as `enum FilterReason` (src/align.rs:33-51) */
+enum {
+  NIMBLE_R_SCORE_BELOW_THRESHOLD = 0,
+  NIMBLE_R_DISCARDED_MULTIPLE_MATCH = 1,
+  NIMBLE_R_DISCARDED_NONZERO_MISMATCH = 2,
+  NIMBLE_R_NO_MATCH = 3,
+  NIMBLE_R_NOT_MATCHING_PAIR = 6,
+  NIMBLE_R_SHORT_READ = 8,
+  NIMBLE_R_HIGH_ENTROPY = 10,
+  NIMBLE_R_SUCCESSFUL_MATCH = 11,
+  NIMBLE_R_ABOVE_MISMATCH_THRESHOLD = 14,
+  NIMBLE_R_NONE = 16
+};
+
+#define NIMBLE_CLASS_NONE 0xFFFFFFFFu /* "Option::None" for an equivalence class */
+
+/* The part of AlignFilterConfig (src/align.rs:79-95) the per-read path reads
+ * (pseudoalign src/align.rs:945-989, filter_alignment_by_metrics src/filter/align.rs:4-45,
+ * require_valid_pair src/align.rs:582-588). */
+typedef struct nimble_align_params {
+  double score_percent;
+  uint64_t score_threshold;
+  uint32_t num_mismatches;
+  uint32_t discard_nonzero_mismatch;
+  uint32_t discard_multiple_matches;
+  uint32_t require_valid_pair;
+  uint32_t min_read_length; /* MIN_READ_LENGTH = 40 (src/align.rs:18) */
+  uint32_t reserved;
+} nimble_align_params;
+
+typedef struct nimble_index nimble_index; /* replaces align::PseudoAligner (src/align.rs:21) */
+typedef struct nimble_ctx nimble_ctx;     /* per-caller workspace: one `score::call` in flight */
+
+/* ---- library / device ---- */
+int nimble_abi_version(void);
+const char *nimble_last_error(void);
+int nimble_device_count(int *count);
+
+/* ---- index: replaces build_index::<Kmer30>(&seqs, &names, &HashMap::new(), threads)
+ *      (src/bin/main.rs:121-128, tests/utils.rs:48-51); input is what
+ *      utils::get_reference_sequence_data (src/utils.rs:7-24) produces: one ASCII sequence per
+ *      library row (fwd and §rev rows interleaved), converted as DnaString::from_acgt_bytes does.
+ *      Names stay on the host.  The index is immutable after build and may be shared by contexts. */
+int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device,
+                       nimble_index **out);
+void nimble_index_free(nimble_index *);
+/* stats[0]=distinct k-mers [1]=unitigs [2]=static classes [3]=unitig bases [4]=static class entries
+ * [5]=hash slots [6]=device bytes [7]=dynamic classes interned so far */
+int nimble_index_stats(const nimble_index *, uint64_t stats[8]);
+/* Equivalence class content (ascending library row ids).  Class ids below stats[2] are the k-mer
+ * colour classes; higher ids are intersections interned on the device.  Returns the class length in
+ * *len; copies at most cap ids. */
+int nimble_class_get(const nimble_index *, uint32_t class_id, uint32_t *ids, uint32_t cap, uint32_t *len);
+
+/* Host-only diagnostic: builds the flat index exactly as nimble_index_build does but uploads nothing.
+ * stats[0..4] as nimble_index_stats.  Lets CPU-only tests check the index builder. */
+int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t stats[5]);
+
+/* ---- context ---- */
+/* stream: a hipStream_t (as void*) to launch on, or NULL for the context's own stream. */
+int nimble_ctx_create(nimble_index *, void *stream, nimble_ctx **out);
+void nimble_ctx_free(nimble_ctx *);
+
+/* Memory space of the read buffers handed to nimble_call */
+enum { NIMBLE_MEM_HOST = 0, NIMBLE_MEM_DEVICE = 1 };
+
+/* ---- the hot path: replaces score::call (src/score.rs:14-46) up to, and excluding, the
+ *      string-level coercion of distinct class pairs (which stays with the host caller).
+ *
+ * One call = one dedup scope, exactly like one `score::call`: reads are keyed by their base string
+ * (R1 string + R2 string, src/align.rs:576-579); identical keys count once (last writer).
+ *
+ *   r1 / r1_off : concatenated ASCII bases of the n reads and n+1 byte offsets.
+ *                 r1_off == NULL means fixed length: read i is r1[i*fixed_len .. (i+1)*fixed_len).
+ *   r2 / r2_off : mates, or r2 == NULL for single-end.
+ *   max_len     : upper bound on any single read length (sizes the packed key and the LDS tiles).
+ *   mem         : NIMBLE_MEM_HOST (buffers are copied) or NIMBLE_MEM_DEVICE (used in place).
+ *
+ * Runs asynchronously on the context's stream; results are read with the getters below, which
+ * synchronise. */
+int nimble_call(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, const uint64_t *r1_off,
+                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len,
+                int mem);
+
+/* Histogram of the call: one entry per distinct (class of R1, class of R2) over the unique read keys
+ * that survived the per-read filters (the `score_map` of src/align.rs:496-505, grouped).
+ * class == NIMBLE_CLASS_NONE where that mate has no passing alignment (PairState First/Second).
+ * Call with cap == 0 to query *n_entries. */
+int nimble_histogram(nimble_ctx *, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count, uint64_t cap,
+                     uint64_t *n_entries);
+
+/* Per-read records of the last call (any pointer may be NULL).  mate = 0 or 1.
+ *   reason : FilterReason code (SUCCESSFUL_MATCH when the mate's alignment was kept)
+ *   score  : bases covered by the walk (0 when there was none)
+ *   mism   : mismatches seen by the walk
+ *   cls    : class id of a kept alignment, else NIMBLE_CLASS_NONE
+ *   counted: 1 for the read that represents its key in the dedup scope */
+int nimble_read_records(nimble_ctx *, int mate, int32_t *reason, int32_t *score, int32_t *mism, uint32_t *cls,
+                        uint8_t *counted, uint64_t n);
+
+/* Counters of the last call: [0]=reads [1]=unique keys kept [2]=seed probes [3]=nodes visited
+ * [4]=class entries read [5]=reads with a seed hit [6]=reads prefiltered [7]=dynamic classes added */
+int nimble_call_counters(nimble_ctx *, uint64_t c[8]);
+
+/* Device time of the stages of the last call, measured with HIP events on the context's stream:
+ * ms[0]=pack ms[1]=align ms[2]=intern ms[3]=dedup ms[4]=count ms[5]=total (first launch to last). */
+int nimble_call_timing(nimble_ctx *, float ms[6]);
+int nimble_ctx_synchronize(nimble_ctx *);
+
+/* Dense count vector over the first n_classes class ids, single-end convenience for multi-GPU
+ * reduction: counts[c] = number of unique keys whose R1 class is c and whose R2 class is NONE.
+ * `counts` is DEVICE memory (int64), written on the context's stream, ready for an RCCL all-reduce. */
+int nimble_histogram_dense_se(nimble_ctx *, int64_t *counts_dev, uint32_t n_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

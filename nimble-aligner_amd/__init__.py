@@ -1,0 +1,261 @@
+"""nimble-aligner_amd -- MI355X-native hot path of nimble-aligner (ctypes binding of the C ABI).
+
+The compute lives in ``lib/libnimble_hip.so`` (hand-written HIP for gfx950, see ``csrc/``) and, above
+it, ``lib/libnimble_host.so`` (C++ mirror of the reference's ``reference_library`` / ``score::call`` /
+FASTQ pipeline, see ``host/``).  This module only loads them and passes pointers; it contains no
+compute and no fallback: if the library is missing, importing the device classes raises.
+
+The directory name has a hyphen, so import it with
+``importlib.import_module("nimble-aligner_amd")``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_LIB_PATH = os.path.join(LIB_DIR, "libnimble_hip.so")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_host.so")
+
+CLASS_NONE = 0xFFFFFFFF
+MEM_HOST, MEM_DEVICE = 0, 1
+
+REASONS = {
+    0: "ScoreBelowThreshold", 1: "DiscardedMultipleMatch", 2: "DiscardedNonzeroMismatch", 3: "NoMatch",
+    6: "NotMatchingPair", 8: "ShortRead", 10: "HighEntropy", 11: "SuccessfulMatch", 14: "AboveMismatchThreshold",
+    16: "None",
+}
+
+
+class NimbleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nimble error %d: %s" % (code, msg))
+        self.code = code
+
+
+class AlignParams(C.Structure):
+    """nimble_align_params (include/nimble_hip.h): the per-read part of AlignFilterConfig."""
+    _fields_ = [
+        ("score_percent", C.c_double),
+        ("score_threshold", C.c_uint64),
+        ("num_mismatches", C.c_uint32),
+        ("discard_nonzero_mismatch", C.c_uint32),
+        ("discard_multiple_matches", C.c_uint32),
+        ("require_valid_pair", C.c_uint32),
+        ("min_read_length", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+    @classmethod
+    def make(cls, score_percent, score_threshold, num_mismatches=0, discard_nonzero_mismatch=False,
+             discard_multiple_matches=False, require_valid_pair=False, min_read_length=40):
+        return cls(float(score_percent), int(score_threshold), int(num_mismatches), int(discard_nonzero_mismatch),
+                   int(discard_multiple_matches), int(require_valid_pair), int(min_read_length), 0)
+
+
+_hip = None
+
+HIP_SYMBOLS = [
+    "nimble_abi_version", "nimble_last_error", "nimble_device_count", "nimble_index_build", "nimble_index_free",
+    "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
+    "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
+    "nimble_call_timing", "nimble_flat_index_stats",
+]
+
+
+def hip_lib():
+    """Load lib/libnimble_hip.so.  Raises if it has not been built -- there is no other backend."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError("nimble-aligner_amd: %s is missing; run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (needs hipcc)" % HIP_LIB_PATH)
+        L = C.CDLL(HIP_LIB_PATH)
+        vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
+        L.nimble_abi_version.restype = i32
+        L.nimble_last_error.restype = C.c_char_p
+        L.nimble_device_count.argtypes = [C.POINTER(i32)]
+        L.nimble_index_build.argtypes = [vp, vp, u32, i32, C.POINTER(vp)]
+        L.nimble_index_free.argtypes = [vp]
+        L.nimble_index_free.restype = None
+        L.nimble_flat_index_stats.argtypes = [vp, vp, u32, C.POINTER(u64)]
+        L.nimble_index_stats.argtypes = [vp, C.POINTER(u64)]
+        L.nimble_class_get.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
+        L.nimble_ctx_create.argtypes = [vp, vp, C.POINTER(vp)]
+        L.nimble_ctx_free.argtypes = [vp]
+        L.nimble_ctx_free.restype = None
+        L.nimble_ctx_synchronize.argtypes = [vp]
+        L.nimble_call.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32]
+        L.nimble_histogram.argtypes = [vp, vp, vp, vp, u64, C.POINTER(u64)]
+        L.nimble_histogram_dense_se.argtypes = [vp, vp, u32]
+        L.nimble_read_records.argtypes = [vp, i32, vp, vp, vp, vp, vp, u64]
+        L.nimble_call_counters.argtypes = [vp, C.POINTER(u64)]
+        L.nimble_call_timing.argtypes = [vp, C.POINTER(C.c_float)]
+        _hip = L
+    return _hip
+
+
+def _check(rc):
+    if rc != 0:
+        raise NimbleError(rc, hip_lib().nimble_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = hip_lib().nimble_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def pack_reads(reads):
+    """list of str/bytes -> (uint8 buffer, uint64 offsets[n+1])"""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return buf, off
+
+
+def _ptr(x):
+    """pointer of a numpy array / torch tensor / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+def flat_index_stats(sequences):
+    """Host-only: statistics of the flat index the builder would upload (no GPU needed)."""
+    buf, off = pack_reads(sequences)
+    s = (C.c_uint64 * 5)()
+    _check(hip_lib().nimble_flat_index_stats(buf.ctypes.data, off.ctypes.data, len(sequences), s))
+    return dict(kmers=s[0], nodes=s[1], classes=s[2], unitig_bases=s[3], class_entries=s[4])
+
+
+class Index:
+    """Device-resident pseudoalignment index: replaces align::PseudoAligner (src/align.rs:21), built as
+    debruijn_mapping::build_index::<Kmer30> is at src/bin/main.rs:121-128."""
+
+    def __init__(self, sequences, device=0):
+        buf, off = pack_reads(sequences)
+        h = C.c_void_p()
+        _check(hip_lib().nimble_index_build(buf.ctypes.data, off.ctypes.data, len(sequences), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        self._class_cache = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            hip_lib().nimble_index_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def stats(self):
+        s = (C.c_uint64 * 8)()
+        _check(hip_lib().nimble_index_stats(self.h, s))
+        return dict(kmers=s[0], nodes=s[1], classes=s[2], unitig_bases=s[3], class_entries=s[4], hash_slots=s[5],
+                    device_bytes=s[6], dynamic_classes=s[7])
+
+    def eq_class(self, class_id):
+        class_id = int(class_id)
+        got = self._class_cache.get(class_id)
+        if got is None:
+            n = C.c_uint32(0)
+            _check(hip_lib().nimble_class_get(self.h, class_id, None, 0, C.byref(n)))
+            a = np.zeros(max(n.value, 1), dtype=np.uint32)
+            _check(hip_lib().nimble_class_get(self.h, class_id, a.ctypes.data, n.value, C.byref(n)))
+            got = a[:n.value].tolist()
+            self._class_cache[class_id] = got
+        return got
+
+
+class Context:
+    """One `score::call` in flight (src/score.rs:14-46): workspace + stream over a shared Index."""
+
+    def __init__(self, index, stream=None):
+        self.index = index
+        h = C.c_void_p()
+        _check(hip_lib().nimble_ctx_create(index.h, stream, C.byref(h)))
+        self.h = h
+        self.n = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            hip_lib().nimble_ctx_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def call(self, params, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST):
+        """nimble_call.  r1/r2: numpy uint8 arrays (host) or torch uint8 tensors / raw pointers (device)."""
+        if r1_off is not None:
+            n = int(len(r1_off) - 1) if n is None else n
+        if n is None:
+            raise ValueError("n is required for fixed-length input")
+        if max_len == 0:
+            if r1_off is not None and isinstance(r1_off, np.ndarray):
+                max_len = int(np.diff(r1_off.astype(np.int64)).max()) if n else 1
+                if r2_off is not None:
+                    max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()) if n else 1)
+            else:
+                max_len = fixed_len
+        self._keep = (r1, r1_off, r2, r2_off)  # keep device inputs alive until the next call
+        _check(hip_lib().nimble_call(self.h, C.byref(params), _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+                                     fixed_len, max_len, mem))
+        self.n = n
+
+    def call_reads(self, params, reads, mates=None):
+        b1, o1 = pack_reads(reads)
+        if mates is not None:
+            b2, o2 = pack_reads(mates)
+            return self.call(params, b1, o1, b2, o2)
+        return self.call(params, b1, o1)
+
+    def synchronize(self):
+        _check(hip_lib().nimble_ctx_synchronize(self.h))
+
+    def histogram(self):
+        """[(class_r1, class_r2, count)] sorted by class ids; CLASS_NONE marks an absent mate call."""
+        ne = C.c_uint64(0)
+        _check(hip_lib().nimble_histogram(self.h, None, None, None, 0, C.byref(ne)))
+        k = ne.value
+        c1 = np.zeros(max(k, 1), dtype=np.uint32)
+        c2 = np.zeros(max(k, 1), dtype=np.uint32)
+        cnt = np.zeros(max(k, 1), dtype=np.uint64)
+        if k:
+            _check(hip_lib().nimble_histogram(self.h, c1.ctypes.data, c2.ctypes.data, cnt.ctypes.data, k,
+                                              C.byref(ne)))
+        return [(int(c1[i]), int(c2[i]), int(cnt[i])) for i in range(k)]
+
+    def histogram_dense_se(self, counts_dev_ptr, n_classes):
+        _check(hip_lib().nimble_histogram_dense_se(self.h, _ptr(counts_dev_ptr), n_classes))
+
+    def read_records(self, mate=0):
+        n = self.n
+        reason = np.zeros(max(n, 1), dtype=np.int32)
+        score = np.zeros(max(n, 1), dtype=np.int32)
+        mism = np.zeros(max(n, 1), dtype=np.int32)
+        cls = np.zeros(max(n, 1), dtype=np.uint32)
+        counted = np.zeros(max(n, 1), dtype=np.uint8)
+        _check(hip_lib().nimble_read_records(self.h, mate, reason.ctypes.data, score.ctypes.data, mism.ctypes.data,
+                                             cls.ctypes.data, counted.ctypes.data, n))
+        return dict(reason=reason[:n], score=score[:n], mismatches=mism[:n], cls=cls[:n], counted=counted[:n])
+
+    def counters(self):
+        c = (C.c_uint64 * 8)()
+        _check(hip_lib().nimble_call_counters(self.h, c))
+        return dict(reads=c[0], unique_keys=c[1], probes=c[2], nodes=c[3], class_entries=c[4], seeded=c[5],
+                    prefiltered=c[6], dynamic_classes=c[7])
+
+    def timing(self):
+        t = (C.c_float * 6)()
+        _check(hip_lib().nimble_call_timing(self.h, t))
+        return dict(pack=t[0], align=t[1], intern=t[2], dedup=t[3], count=t[4], total=t[5])

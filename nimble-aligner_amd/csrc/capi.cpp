@@ -1,0 +1,692 @@
+// capi.cpp -- implementation of the C ABI declared in include/nimble_hip.h.
+//
+// Owns device memory, streams and the launch sequence of one `score::call` (src/score.rs:14-46):
+//   pack -> align -> intern (claim / verify rounds) -> dedup -> count
+// There is no CPU path here: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "flat_index.h"
+#include "kernels.h"
+
+using namespace nimble;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(NIMBLE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+uint64_t env_u64(const char *name, uint64_t dflt) {
+  const char *v = getenv(name);
+  if (!v || !*v) return dflt;
+  return strtoull(v, nullptr, 10);
+}
+
+uint64_t pow2_at_least(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// growable device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes, uint64_t *total) {
+    if (bytes <= cap) return NIMBLE_OK;
+    if (p) {
+      (void)hipFree(p);
+      if (total) *total -= cap;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = bytes + 64;  // tail padding: 16-byte vector loads may touch the last partial chunk
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return fail(NIMBLE_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    cap = bytes;
+    if (total) *total += cap;
+    return NIMBLE_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct nimble_index {
+  int device = 0;
+  DevIndex dev{};
+  DevBuf b_ht, b_hdr, b_redge, b_ledge, b_unitig, b_cls_off, b_cls_len, b_cls_ids, b_intern, b_dyn_state;
+  uint64_t device_bytes = 0;
+  uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
+  std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
+  ~nimble_index() {
+    for (DevBuf *b : {&b_ht, &b_hdr, &b_redge, &b_ledge, &b_unitig, &b_cls_off, &b_cls_len, &b_cls_ids, &b_intern,
+                      &b_dyn_state})
+      b->release();
+  }
+};
+
+struct nimble_ctx {
+  nimble_index *ix = nullptr;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  CallBuffers cb{};
+  uint64_t bytes = 0;
+  DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
+      b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
+  DevBuf b_in[2], b_in_off[2];  // staging of host inputs
+  DevBuf b_plog;
+  uint32_t plog_max_len = 0;
+  DevBuf b_out_c1, b_out_c2, b_out_cnt;
+  uint64_t scratch_cap = 0;
+  uint64_t hist_slots = 0;
+  hipEvent_t ev[7] = {};
+  bool have_events = false;
+  bool called = false;
+  int want_counters = 1;
+  uint32_t dyn_before = 0, dyn_after = 0;
+  std::vector<uint64_t> h_state = std::vector<uint64_t>(16, 0);
+  ~nimble_ctx() {
+    for (DevBuf *b : {&b_keys, &b_len[0], &b_len[1], &b_hash, &b_pre[0], &b_pre[1], &b_reason[0], &b_reason[1],
+                      &b_score[0], &b_score[1], &b_mism[0], &b_mism[1], &b_cls[0], &b_cls[1], &b_dyn_off[0],
+                      &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
+                      &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
+                      &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_out_c1, &b_out_c2,
+                      &b_out_cnt})
+      b->release();
+    if (have_events)
+      for (auto &e : ev) (void)hipEventDestroy(e);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+template <class T>
+int upload(DevBuf &b, const std::vector<T> &v, uint64_t *total, size_t min_elems = 0) {
+  size_t n = std::max(v.size(), min_elems);
+  int rc = b.ensure(std::max<size_t>(n * sizeof(T), 16), total);
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return NIMBLE_OK;
+}
+
+int ensure_plog(nimble_ctx *c, uint32_t max_len) {
+  if (c->b_plog.p && c->plog_max_len >= max_len) return NIMBLE_OK;
+  // row L (L+1 entries, at offset L(L+1)/2): (k/L) * log2(k/L) in IEEE double, the terms of
+  // utils::shannon_entropy (src/utils.rs:111-116); computed by the host libm so that the device sum
+  // reproduces the CPU value bit for bit
+  uint32_t m = std::max<uint32_t>(max_len, 256);
+  std::vector<double> t(((size_t)m + 1) * (m + 2) / 2, 0.0);
+  for (uint32_t L = 1; L <= m; ++L) {
+    double *row = t.data() + ((size_t)L * (L + 1)) / 2;
+    for (uint32_t k = 1; k <= L; ++k) {
+      double f = (double)k / (double)L;
+      row[k] = f * std::log2(f);
+    }
+  }
+  int rc = upload(c->b_plog, t, &c->bytes);
+  if (rc) return rc;
+  c->plog_max_len = m;
+  return NIMBLE_OK;
+}
+
+int fetch_state(nimble_ctx *c) {
+  HIPCHK(hipMemcpyAsync(c->h_state.data(), c->b_state.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NIMBLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nimble_abi_version(void) { return NIMBLE_ABI_VERSION; }
+const char *nimble_last_error(void) { return g_err.c_str(); }
+
+int nimble_device_count(int *count) {
+  if (!count) return fail(NIMBLE_E_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(NIMBLE_E_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return NIMBLE_OK;
+}
+
+int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device, nimble_index **out) {
+  if (!out || (!seqs && n_seqs) || !seq_off) return fail(NIMBLE_E_INVALID, "nimble_index_build: NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NIMBLE_E_NO_DEVICE, "nimble_index_build: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(NIMBLE_E_INVALID, "nimble_index_build: bad device ordinal");
+  HIPCHK(hipSetDevice(device));
+  FlatIndex fi;
+  try {
+    build_flat_index(seqs, seq_off, n_seqs, fi);
+  } catch (const std::bad_alloc &) {
+    return fail(NIMBLE_E_NOMEM, "nimble_index_build: out of host memory");
+  } catch (const std::exception &e) {
+    return fail(NIMBLE_E_INTERNAL, e.what());
+  }
+  nimble_index *ix = new (std::nothrow) nimble_index();
+  if (!ix) return fail(NIMBLE_E_NOMEM, "out of memory");
+  ix->device = device;
+  ix->n_kmers = fi.n_kmers;
+  ix->n_nodes = fi.n_nodes;
+  ix->n_static = fi.n_colours;
+  ix->unitig_bases = fi.unitig_bases;
+  ix->static_entries = fi.col_ids.size();
+  ix->ht_slots = fi.ht_slots;
+  const uint64_t dyn_classes = env_u64("NIMBLE_DYN_CLASSES", 1ULL << 20);
+  const uint64_t dyn_ids = env_u64("NIMBLE_DYN_IDS", 1ULL << 26);
+  const uint64_t cls_cap = fi.n_colours + dyn_classes;
+  const uint64_t ids_cap = fi.col_ids.size() + dyn_ids;
+  if (cls_cap >= 0xFFFFFFF0ULL || ids_cap >= 0xFFFFFFF0ULL) {
+    delete ix;
+    return fail(NIMBLE_E_INVALID, "class table capacity exceeds 32 bits");
+  }
+  int rc = NIMBLE_OK;
+  auto up = [&](auto &buf, const auto &vec, size_t min_elems = 0) {
+    if (rc == NIMBLE_OK) rc = upload(buf, vec, &ix->device_bytes, min_elems);
+  };
+  up(ix->b_ht, fi.ht);
+  up(ix->b_hdr, fi.node_hdr);
+  up(ix->b_redge, fi.node_redge);
+  up(ix->b_ledge, fi.node_ledge);
+  up(ix->b_unitig, fi.unitig);
+  std::vector<uint32_t> off(fi.col_off.begin(), fi.col_off.end() - 1), len(fi.n_colours);
+  for (size_t c = 0; c < fi.n_colours; ++c) len[c] = fi.col_off[c + 1] - fi.col_off[c];
+  up(ix->b_cls_off, off, cls_cap);
+  up(ix->b_cls_len, len, cls_cap);
+  up(ix->b_cls_ids, fi.col_ids, ids_cap);
+  // intern table seeded with the static classes, so that an intersection equal to a k-mer colour
+  // resolves to that colour's id (class ids are canonical by content)
+  const uint64_t islots = pow2_at_least(4 * cls_cap);
+  std::vector<uint64_t> intern(islots, 0);
+  for (size_t c = 0; c < fi.n_colours; ++c) {
+    uint64_t h = class_hash_init();
+    for (uint32_t t = fi.col_off[c]; t < fi.col_off[c + 1]; ++t) h = class_hash_step(h, fi.col_ids[t]);
+    h = class_hash_final(h, len[c]);
+    uint64_t pos = h & (islots - 1);
+    while (intern[pos] != 0) pos = (pos + 1) & (islots - 1);
+    intern[pos] = ((uint64_t)intern_tag(h) << 32) | (uint32_t)c;
+  }
+  up(ix->b_intern, intern);
+  std::vector<uint32_t> dyn_state = {(uint32_t)fi.n_colours, (uint32_t)fi.col_ids.size(), 0, 0};
+  up(ix->b_dyn_state, dyn_state);
+  if (rc != NIMBLE_OK) {
+    delete ix;
+    return rc;
+  }
+  ix->h_col_off = std::move(fi.col_off);
+  ix->h_col_ids = std::move(fi.col_ids);
+  DevIndex &d = ix->dev;
+  d.ht = ix->b_ht.as<uint4>();
+  d.ht_mask = fi.ht_slots - 1;
+  d.node_hdr = ix->b_hdr.as<uint4>();
+  d.node_redge = ix->b_redge.as<uint4>();
+  d.node_ledge = ix->b_ledge.as<uint4>();
+  d.unitig = ix->b_unitig.as<uint64_t>();
+  d.cls_off = ix->b_cls_off.as<uint32_t>();
+  d.cls_len = ix->b_cls_len.as<uint32_t>();
+  d.cls_ids = ix->b_cls_ids.as<uint32_t>();
+  d.n_static = (uint32_t)fi.n_colours;
+  d.cls_cap = (uint32_t)cls_cap;
+  d.ids_cap = (uint32_t)ids_cap;
+  d.intern = ix->b_intern.as<uint64_t>();
+  d.intern_mask = islots - 1;
+  d.dyn_state = ix->b_dyn_state.as<uint32_t>();
+  *out = ix;
+  return NIMBLE_OK;
+}
+
+int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t s[5]) {
+  if ((!seqs && n_seqs) || !seq_off || !s) return fail(NIMBLE_E_INVALID, "nimble_flat_index_stats: NULL argument");
+  try {
+    FlatIndex fi;
+    build_flat_index(seqs, seq_off, n_seqs, fi);
+    s[0] = fi.n_kmers;
+    s[1] = fi.n_nodes;
+    s[2] = fi.n_colours;
+    s[3] = fi.unitig_bases;
+    s[4] = fi.col_ids.size();
+  } catch (const std::exception &e) {
+    return fail(NIMBLE_E_INTERNAL, e.what());
+  }
+  return NIMBLE_OK;
+}
+
+void nimble_index_free(nimble_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  delete ix;
+}
+
+int nimble_index_stats(const nimble_index *ix, uint64_t s[8]) {
+  if (!ix || !s) return fail(NIMBLE_E_INVALID, "nimble_index_stats: NULL argument");
+  s[0] = ix->n_kmers;
+  s[1] = ix->n_nodes;
+  s[2] = ix->n_static;
+  s[3] = ix->unitig_bases;
+  s[4] = ix->static_entries;
+  s[5] = ix->ht_slots;
+  s[6] = ix->device_bytes;
+  uint32_t st[4] = {0, 0, 0, 0};
+  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(hipMemcpy(st, ix->b_dyn_state.p, sizeof(st), hipMemcpyDeviceToHost));
+  s[7] = st[0] - ix->n_static;
+  return NIMBLE_OK;
+}
+
+int nimble_class_get(const nimble_index *ix, uint32_t id, uint32_t *ids, uint32_t cap, uint32_t *len) {
+  if (!ix || !len) return fail(NIMBLE_E_INVALID, "nimble_class_get: NULL argument");
+  if (id < ix->n_static) {
+    uint32_t o = ix->h_col_off[id], l = ix->h_col_off[id + 1] - o;
+    *len = l;
+    if (ids) memcpy(ids, ix->h_col_ids.data() + o, sizeof(uint32_t) * std::min(l, cap));
+    return NIMBLE_OK;
+  }
+  HIPCHK(hipSetDevice(ix->device));
+  uint32_t st[4];
+  HIPCHK(hipMemcpy(st, ix->b_dyn_state.p, sizeof(st), hipMemcpyDeviceToHost));
+  if (id >= st[0] || id >= ix->dev.cls_cap) return fail(NIMBLE_E_INVALID, "nimble_class_get: unknown class id");
+  uint32_t o = 0, l = 0;
+  HIPCHK(hipMemcpy(&o, ix->dev.cls_off + id, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&l, ix->dev.cls_len + id, 4, hipMemcpyDeviceToHost));
+  *len = l;
+  if (ids && l && cap)
+    HIPCHK(hipMemcpy(ids, ix->dev.cls_ids + o, sizeof(uint32_t) * std::min(l, cap), hipMemcpyDeviceToHost));
+  return NIMBLE_OK;
+}
+
+int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
+  if (!ix || !out) return fail(NIMBLE_E_INVALID, "nimble_ctx_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(ix->device));
+  nimble_ctx *c = new (std::nothrow) nimble_ctx();
+  if (!c) return fail(NIMBLE_E_NOMEM, "out of memory");
+  c->ix = ix;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(NIMBLE_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  for (auto &e : c->ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return fail(NIMBLE_E_HIP, "hipEventCreate failed");
+    }
+  }
+  c->have_events = true;
+  c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 1);
+  *out = c;
+  return NIMBLE_OK;
+}
+
+void nimble_ctx_free(nimble_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ix->device);
+  (void)hipStreamSynchronize(c->stream);
+  delete c;
+}
+
+int nimble_ctx_synchronize(nimble_ctx *c) {
+  if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NIMBLE_OK;
+}
+
+int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
+                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call: NULL argument");
+  if (n && !r1) return fail(NIMBLE_E_INVALID, "nimble_call: r1 is NULL");
+  if (!r1_off && fixed_len == 0 && n) return fail(NIMBLE_E_INVALID, "nimble_call: neither offsets nor fixed_len given");
+  if (r2 && ((r1_off == nullptr) != (r2_off == nullptr)))
+    return fail(NIMBLE_E_INVALID, "nimble_call: R1 and R2 must both use offsets or both be fixed length");
+  if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_call: more than 2^32 reads in one call");
+  if (!r1_off && fixed_len > max_len) max_len = fixed_len;
+  if (max_len == 0) max_len = 1;
+  if (max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call: max_len above 65535 is not supported");
+  if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE) return fail(NIMBLE_E_INVALID, "nimble_call: bad mem");
+  nimble_index *ix = c->ix;
+  HIPCHK(hipSetDevice(ix->device));
+  hipStream_t s = c->stream;
+  const bool paired = r2 != nullptr;
+  const int nm = paired ? 2 : 1;
+  const uint32_t kw = (max_len * (uint32_t)nm + 31u) / 32u;
+  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 > 64 * 1024)
+    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~960)");
+
+  // ---- inputs
+  const uint8_t *d_r[2] = {r1, r2};
+  const uint64_t *d_off[2] = {r1_off, r2_off};
+  if (mem == NIMBLE_MEM_HOST) {
+    for (int m = 0; m < nm; ++m) {
+      const uint8_t *src = m ? r2 : r1;
+      const uint64_t *off = m ? r2_off : r1_off;
+      uint64_t bytes = off ? off[n] : n * (uint64_t)fixed_len;
+      if (off) {
+        for (uint64_t i = 0; i < n; ++i)
+          if (off[i + 1] < off[i] || off[i + 1] - off[i] > max_len)
+            return fail(NIMBLE_E_INVALID, "nimble_call: offsets not monotone or a read longer than max_len");
+      }
+      int rc = c->b_in[m].ensure(std::max<uint64_t>(bytes, 16), &c->bytes);
+      if (rc) return rc;
+      if (bytes) HIPCHK(hipMemcpyAsync(c->b_in[m].p, src, bytes, hipMemcpyHostToDevice, s));
+      d_r[m] = c->b_in[m].as<uint8_t>();
+      if (off) {
+        rc = c->b_in_off[m].ensure((n + 1) * 8, &c->bytes);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->b_in_off[m].p, off, (n + 1) * 8, hipMemcpyHostToDevice, s));
+        d_off[m] = c->b_in_off[m].as<uint64_t>();
+      }
+    }
+  }
+
+  // ---- per-call buffers
+  CallBuffers &cb = c->cb;
+  cb.n = n;
+  cb.key_words = kw;
+  cb.paired = paired ? 1 : 0;
+  const size_t nn = std::max<uint64_t>(n, 1);
+  int rc = NIMBLE_OK;
+  auto need = [&](DevBuf &b, size_t bytes) {
+    if (rc == NIMBLE_OK) rc = b.ensure(bytes, &c->bytes);
+  };
+  need(c->b_keys, nn * kw * 8);
+  need(c->b_hash, nn * 8);
+  need(c->b_slot, nn * 4);
+  need(c->b_counted, nn);
+  for (int m = 0; m < 2; ++m) {
+    need(c->b_len[m], nn * 4);
+    need(c->b_pre[m], nn);
+    need(c->b_reason[m], nn);
+    need(c->b_score[m], nn * 4);
+    need(c->b_mism[m], nn * 4);
+    need(c->b_cls[m], nn * 4);
+    need(c->b_dyn_off[m], nn * 4);
+    need(c->b_dyn_len[m], nn * 4);
+    need(c->b_dyn_hash[m], nn * 8);
+    need(c->b_dyn_pos[m], nn * 4);
+  }
+  if (c->scratch_cap == 0) c->scratch_cap = std::max<uint64_t>(1ULL << 20, env_u64("NIMBLE_SCRATCH_PER_READ", 4) * n);
+  c->scratch_cap = std::min<uint64_t>(std::max<uint64_t>(c->scratch_cap, env_u64("NIMBLE_SCRATCH_PER_READ", 4) * n),
+                                      0xFFFFFF00ULL);
+  need(c->b_scratch, c->scratch_cap * 4);
+  const uint32_t ws_rows = max_len > align_lds_cols() ? max_len - align_lds_cols() : 0;
+  need(c->b_ws, std::max<size_t>((size_t)ws_rows * align_ws_lanes() * 4, 16));
+  const uint64_t dslots = pow2_at_least(std::max<uint64_t>(2 * n, 1024));
+  need(c->b_dedup, dslots * 8);
+  if (c->hist_slots == 0) c->hist_slots = pow2_at_least(env_u64("NIMBLE_HIST_SLOTS", 1ULL << 20));
+  need(c->b_hist_keys, c->hist_slots * 8);
+  need(c->b_hist_cnt, c->hist_slots * 8);
+  need(c->b_state, 16 * 8);
+  if (rc != NIMBLE_OK) return rc;
+  rc = ensure_plog(c, max_len);
+  if (rc != NIMBLE_OK) return rc;
+
+  cb.keys = c->b_keys.as<uint64_t>();
+  cb.key_hash = c->b_hash.as<uint64_t>();
+  cb.slot = c->b_slot.as<uint32_t>();
+  cb.counted = c->b_counted.as<uint8_t>();
+  for (int m = 0; m < 2; ++m) {
+    cb.len[m] = c->b_len[m].as<uint32_t>();
+    cb.pre[m] = c->b_pre[m].as<uint8_t>();
+    cb.reason[m] = c->b_reason[m].as<uint8_t>();
+    cb.score[m] = c->b_score[m].as<uint32_t>();
+    cb.mism[m] = c->b_mism[m].as<uint32_t>();
+    cb.cls[m] = c->b_cls[m].as<uint32_t>();
+    cb.dyn_off[m] = c->b_dyn_off[m].as<uint32_t>();
+    cb.dyn_len[m] = c->b_dyn_len[m].as<uint32_t>();
+    cb.dyn_hash[m] = c->b_dyn_hash[m].as<uint64_t>();
+    cb.dyn_pos[m] = c->b_dyn_pos[m].as<uint32_t>();
+  }
+  cb.scratch = c->b_scratch.as<uint32_t>();
+  cb.scratch_cap = (uint32_t)c->scratch_cap;
+  cb.ws_cols = c->b_ws.as<uint32_t>();
+  cb.ws_rows = ws_rows;
+  cb.ws_lanes = align_ws_lanes();
+  cb.dedup = c->b_dedup.as<uint64_t>();
+  cb.dedup_mask = dslots - 1;
+  cb.hist_keys = c->b_hist_keys.as<uint64_t>();
+  cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
+  cb.hist_mask = c->hist_slots - 1;
+  cb.state = c->b_state.as<uint64_t>();
+
+  uint32_t dst[4];
+  HIPCHK(hipMemcpyAsync(dst, ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  c->dyn_before = dst[0];
+
+  nimble_align_params prm = *p;
+  if (prm.min_read_length == 0) prm.min_read_length = 40;
+
+  for (int attempt = 0;; ++attempt) {
+    HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
+    HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, dslots * 8, s));
+    HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
+    HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+    if (!paired) HIPCHK(hipMemsetAsync(c->b_len[1].p, 0, nn * 4, s));
+
+    HIPCHK(hipEventRecord(c->ev[0], s));
+    launch_pack(s, d_r[0], d_off[0], d_r[1], d_off[1], fixed_len, max_len, prm.min_read_length,
+                c->b_plog.as<double>(), c->plog_max_len, cb);
+    HIPCHK(hipEventRecord(c->ev[1], s));
+    launch_align(s, ix->dev, prm, cb, c->want_counters);
+    HIPCHK(hipEventRecord(c->ev[2], s));
+    // intern rounds: claim, then verify after the kernel boundary; repeat while tag collisions remain
+    bool retry = false;
+    for (int round = 0;; ++round) {
+      launch_intern_claim(s, ix->dev, cb, round);
+      launch_intern_verify(s, ix->dev, cb);
+      rc = fetch_state(c);
+      if (rc) return rc;
+      uint64_t err = c->h_state[10];
+      if (err & ERR_SCRATCH) {
+        if (attempt >= 3 || c->scratch_cap >= 0xFFFFFF00ULL)
+          return fail(NIMBLE_E_OVERFLOW, "class scratch pool overflow (raise NIMBLE_SCRATCH_PER_READ)");
+        c->scratch_cap = std::min<uint64_t>(c->scratch_cap * 4, 0xFFFFFF00ULL);
+        rc = c->b_scratch.ensure(c->scratch_cap * 4, &c->bytes);
+        if (rc) return rc;
+        cb.scratch = c->b_scratch.as<uint32_t>();
+        cb.scratch_cap = (uint32_t)c->scratch_cap;
+        retry = true;
+        break;
+      }
+      if (err & ERR_CLASS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class table full (raise NIMBLE_DYN_CLASSES)");
+      if (err & ERR_IDS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class id pool full (raise NIMBLE_DYN_IDS)");
+      if (c->h_state[9] == 0) break;
+      if (round > 64) return fail(NIMBLE_E_INTERNAL, "class interning did not converge");
+      HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 9, 0, 8, s));
+    }
+    if (retry) continue;
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    launch_dedup(s, prm, cb);
+    HIPCHK(hipEventRecord(c->ev[4], s));
+    launch_count(s, cb);
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    break;
+  }
+  HIPCHK(hipGetLastError());
+  c->called = true;
+  return NIMBLE_OK;
+}
+
+static int finish_count_stage(nimble_ctx *c) {
+  // histogram table overflow is detected after the fact; grow and redo the count stage
+  for (int attempt = 0;; ++attempt) {
+    int rc = fetch_state(c);
+    if (rc) return rc;
+    if (!(c->h_state[10] & ERR_HIST)) return NIMBLE_OK;
+    if (attempt >= 4) return fail(NIMBLE_E_OVERFLOW, "histogram table overflow");
+    c->hist_slots *= 16;
+    rc = c->b_hist_keys.ensure(c->hist_slots * 8, &c->bytes);
+    if (rc) return rc;
+    rc = c->b_hist_cnt.ensure(c->hist_slots * 8, &c->bytes);
+    if (rc) return rc;
+    CallBuffers &cb = c->cb;
+    cb.hist_keys = c->b_hist_keys.as<uint64_t>();
+    cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
+    cb.hist_mask = c->hist_slots - 1;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
+    HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+    HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 10, 0, 8, s));
+    launch_count(s, cb);
+  }
+}
+
+int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count, uint64_t cap,
+                     uint64_t *n_entries) {
+  if (!c || !n_entries) return fail(NIMBLE_E_INVALID, "nimble_histogram: NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram: no call has been made on this context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const uint64_t slots = c->hist_slots;
+  rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
+  if (!rc) rc = c->b_out_c2.ensure(slots * 4, &c->bytes);
+  if (!rc) rc = c->b_out_cnt.ensure(slots * 8, &c->bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, s));
+  launch_hist_compact(s, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(), c->b_out_cnt.as<uint64_t>(),
+                      slots);
+  rc = fetch_state(c);
+  if (rc) return rc;
+  const uint64_t ne = c->h_state[11];
+  *n_entries = ne;
+  if (cap == 0 || ne == 0) return NIMBLE_OK;
+  if (!class_r1 || !class_r2 || !count) return fail(NIMBLE_E_INVALID, "nimble_histogram: NULL output");
+  std::vector<uint32_t> a(ne), b(ne);
+  std::vector<uint64_t> k(ne);
+  HIPCHK(hipMemcpy(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> order(ne);
+  for (uint64_t i = 0; i < ne; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+    return a[x] != a[y] ? a[x] < a[y] : b[x] < b[y];
+  });
+  for (uint64_t i = 0; i < ne && i < cap; ++i) {
+    class_r1[i] = a[order[i]];
+    class_r2[i] = b[order[i]];
+    count[i] = k[order[i]];
+  }
+  return NIMBLE_OK;
+}
+
+int nimble_histogram_dense_se(nimble_ctx *c, int64_t *counts_dev, uint32_t n_classes) {
+  if (!c || !counts_dev) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: no call has been made");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(counts_dev, 0, (size_t)n_classes * 8, c->stream));
+  launch_hist_dense_se(c->stream, c->cb, counts_dev, n_classes);
+  HIPCHK(hipGetLastError());
+  return NIMBLE_OK;
+}
+
+int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score, int32_t *mism, uint32_t *cls,
+                        uint8_t *counted, uint64_t n) {
+  if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
+  if (!c->called || n != c->cb.n) return fail(NIMBLE_E_INVALID, "nimble_read_records: n does not match the last call");
+  if (mate < 0 || mate > 1) return fail(NIMBLE_E_INVALID, "nimble_read_records: mate must be 0 or 1");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  if (n == 0) return NIMBLE_OK;
+  if (mate == 1 && !c->cb.paired) {
+    for (uint64_t i = 0; i < n; ++i) {
+      if (reason) reason[i] = NIMBLE_R_SUCCESSFUL_MATCH;  // src/align.rs:596-599: no mate filter -> SuccessfulMatch
+      if (score) score[i] = 0;
+      if (mism) mism[i] = 0;
+      if (cls) cls[i] = NIMBLE_CLASS_NONE;
+    }
+    if (counted) HIPCHK(hipMemcpy(counted, c->cb.counted, n, hipMemcpyDeviceToHost));
+    return NIMBLE_OK;
+  }
+  if (reason) {
+    std::vector<uint8_t> t(n);
+    HIPCHK(hipMemcpy(t.data(), c->cb.reason[mate], n, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) reason[i] = t[i];
+  }
+  if (score) HIPCHK(hipMemcpy(score, c->cb.score[mate], n * 4, hipMemcpyDeviceToHost));
+  if (mism) HIPCHK(hipMemcpy(mism, c->cb.mism[mate], n * 4, hipMemcpyDeviceToHost));
+  if (cls) HIPCHK(hipMemcpy(cls, c->cb.cls[mate], n * 4, hipMemcpyDeviceToHost));
+  if (counted) HIPCHK(hipMemcpy(counted, c->cb.counted, n, hipMemcpyDeviceToHost));
+  return NIMBLE_OK;
+}
+
+int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
+  if (!c || !out) return fail(NIMBLE_E_INVALID, "NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_call_counters: no call has been made");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  uint64_t ne = 0;
+  rc = nimble_histogram(c, nullptr, nullptr, nullptr, 0, &ne);
+  if (rc) return rc;
+  uint64_t uniq = 0;
+  if (ne) {
+    std::vector<uint64_t> k(ne);
+    HIPCHK(hipMemcpy(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost));
+    for (uint64_t v : k) uniq += v;
+  }
+  uint32_t dst[4];
+  HIPCHK(hipMemcpy(dst, c->ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost));
+  out[0] = c->cb.n;
+  out[1] = uniq;
+  for (int i = 2; i <= 6; ++i) out[i] = c->h_state[i];
+  out[7] = dst[0] - c->dyn_before;
+  return NIMBLE_OK;
+}
+
+int nimble_call_timing(nimble_ctx *c, float ms[6]) {
+  if (!c || !ms) return fail(NIMBLE_E_INVALID, "NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_call_timing: no call has been made");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipEventSynchronize(c->ev[5]));
+  for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  HIPCHK(hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+  return NIMBLE_OK;
+}
+
+}  // extern "C"

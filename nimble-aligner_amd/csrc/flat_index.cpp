@@ -1,0 +1,201 @@
+// flat_index.cpp -- sort-based construction of the flat device index (see flat_index.h).
+//
+// Semantics (external crate behaviour at src/bin/main.rs:121-128):
+//   * every 30-mer of every row, stranded; colour = ascending set of row ids containing it
+//   * extensions of a k-mer = union of the neighbouring bases observed in the rows
+//   * k-mers x -> y are joined iff x has one right extension, y one left extension and equal colour;
+//     chains of joins are the unitigs; a pure cycle is cut in front of its smallest k-mer
+//   * dictionary k-mer -> (unitig, offset); edges of a unitig = unitigs starting/ending with the
+//     neighbour k-mer of its terminal k-mers
+#include "flat_index.h"
+
+#include <algorithm>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace nimble {
+namespace {
+
+struct Occ {
+  uint64_t kmer;
+  uint32_t seq;
+  uint32_t exts;  // lext | rext << 4
+};
+
+inline int popc4(uint32_t m) { return __builtin_popcount(m & 0xF); }
+
+}  // namespace
+
+void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs, FlatIndex &out) {
+  // 1. all k-mer occurrences
+  uint64_t total = 0;
+  for (uint32_t s = 0; s < n_seqs; ++s) {
+    uint64_t len = off[s + 1] - off[s];
+    if (len >= KMER) total += len - KMER + 1;
+  }
+  std::vector<Occ> occ;
+  occ.reserve(total);
+  for (uint32_t s = 0; s < n_seqs; ++s) {
+    const uint8_t *p = seqs + off[s];
+    uint64_t len = off[s + 1] - off[s];
+    if (len < KMER) continue;
+    uint64_t km = 0;
+    for (uint32_t i = 0; i < KMER - 1; ++i) km = (km << 2) | encode_base(p[i]);
+    for (uint64_t pos = 0; pos + KMER <= len; ++pos) {
+      km = ((km << 2) | encode_base(p[pos + KMER - 1])) & KMER_MASK;
+      uint32_t l = pos > 0 ? 1u << encode_base(p[pos - 1]) : 0u;
+      uint32_t r = pos + KMER < len ? 1u << encode_base(p[pos + KMER]) : 0u;
+      occ.push_back(Occ{km, s, l | (r << 4)});
+    }
+  }
+  std::sort(occ.begin(), occ.end(),
+            [](const Occ &a, const Occ &b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
+
+  // 2. distinct k-mers, their extension masks and colour classes (interned by content)
+  std::vector<uint64_t> kmers;
+  std::vector<uint8_t> exts;
+  std::vector<uint32_t> colour;
+  out.col_off.assign(1, 0);
+  out.col_ids.clear();
+  std::unordered_multimap<uint64_t, uint32_t> by_hash;
+  std::vector<uint32_t> ids;
+  for (size_t i = 0; i < occ.size();) {
+    size_t j = i;
+    uint32_t e = 0;
+    ids.clear();
+    while (j < occ.size() && occ[j].kmer == occ[i].kmer) {
+      e |= occ[j].exts;
+      if (ids.empty() || ids.back() != occ[j].seq) ids.push_back(occ[j].seq);
+      ++j;
+    }
+    uint64_t h = class_hash_init();
+    for (uint32_t v : ids) h = class_hash_step(h, v);
+    h = class_hash_final(h, (uint32_t)ids.size());
+    uint32_t cid = UINT32_MAX;
+    auto range = by_hash.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+      uint32_t c = it->second;
+      uint32_t len = out.col_off[c + 1] - out.col_off[c];
+      if (len == ids.size() && std::equal(ids.begin(), ids.end(), out.col_ids.begin() + out.col_off[c])) {
+        cid = c;
+        break;
+      }
+    }
+    if (cid == UINT32_MAX) {
+      cid = (uint32_t)out.col_off.size() - 1;
+      out.col_ids.insert(out.col_ids.end(), ids.begin(), ids.end());
+      out.col_off.push_back((uint32_t)out.col_ids.size());
+      by_hash.emplace(h, cid);
+    }
+    kmers.push_back(occ[i].kmer);
+    exts.push_back((uint8_t)e);
+    colour.push_back(cid);
+    i = j;
+  }
+  std::vector<Occ>().swap(occ);
+  const size_t n = kmers.size();
+  out.n_kmers = n;
+  out.n_colours = out.col_off.size() - 1;
+
+  auto find = [&](uint64_t km) -> size_t {
+    size_t p = std::lower_bound(kmers.begin(), kmers.end(), km) - kmers.begin();
+    if (p >= n || kmers[p] != km) throw std::runtime_error("index build: neighbour k-mer missing");
+    return p;
+  };
+
+  // 3. join relation next[]/prev[] (UINT32_MAX = none)
+  if (n >= UINT32_MAX) throw std::runtime_error("index build: too many k-mers");
+  std::vector<uint32_t> next(n, UINT32_MAX), prev(n, UINT32_MAX);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t r = exts[i] >> 4;
+    if (popc4(r) != 1) continue;
+    uint64_t nk = ((kmers[i] << 2) | (uint64_t)__builtin_ctz(r)) & KMER_MASK;
+    size_t j = find(nk);
+    if (popc4(exts[j] & 0xF) != 1 || colour[j] != colour[i]) continue;
+    next[i] = (uint32_t)j;
+    prev[j] = (uint32_t)i;
+  }
+  // cut pure cycles in front of their smallest k-mer: walk chains from heads first, then leftovers
+  std::vector<uint8_t> seen(n, 0);
+  std::vector<uint32_t> heads;
+  for (size_t i = 0; i < n; ++i)
+    if (prev[i] == UINT32_MAX) {
+      heads.push_back((uint32_t)i);
+      for (uint32_t c = (uint32_t)i; c != UINT32_MAX; c = next[c]) seen[c] = 1;
+    }
+  for (size_t i = 0; i < n; ++i)
+    if (!seen[i]) {  // smallest member of a cycle (ascending scan)
+      uint32_t p = prev[i];
+      next[p] = UINT32_MAX;
+      prev[i] = UINT32_MAX;
+      heads.push_back((uint32_t)i);
+      for (uint32_t c = (uint32_t)i; c != UINT32_MAX; c = next[c]) seen[c] = 1;
+    }
+  std::sort(heads.begin(), heads.end());
+
+  // 4. unitigs
+  const size_t n_nodes = heads.size();
+  out.n_nodes = n_nodes;
+  out.node_hdr.assign(n_nodes * 4, 0);
+  out.node_redge.assign(n_nodes * 4, 0);
+  out.node_ledge.assign(n_nodes * 4, 0);
+  std::vector<uint32_t> kmer_node(n), kmer_off(n);
+  std::vector<uint32_t> tail(n_nodes);
+  uint64_t bases = 0;
+  for (size_t nd = 0; nd < n_nodes; ++nd) {
+    uint32_t o = 0, c = heads[nd], last = c;
+    for (; c != UINT32_MAX; c = next[c]) {
+      kmer_node[c] = (uint32_t)nd;
+      kmer_off[c] = o++;
+      last = c;
+    }
+    tail[nd] = last;
+    uint64_t len = (uint64_t)o + KMER - 1;
+    if (bases + len >= (1ULL << 32)) throw std::runtime_error("index build: unitig buffer exceeds 2^32 bases");
+    out.node_hdr[nd * 4 + 0] = (uint32_t)bases;
+    out.node_hdr[nd * 4 + 1] = (uint32_t)len;
+    out.node_hdr[nd * 4 + 2] = colour[heads[nd]];
+    out.node_hdr[nd * 4 + 3] = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
+    bases += len;
+  }
+  out.unitig_bases = bases;
+  out.unitig.assign((bases + 31) / 32 + 4, 0);  // +4 words so a 3-word window never reads past the end
+  auto put_base = [&](uint64_t pos, uint64_t b) { out.unitig[pos >> 5] |= b << (62 - 2 * (pos & 31)); };
+  for (size_t nd = 0; nd < n_nodes; ++nd) {
+    uint64_t pos = out.node_hdr[nd * 4 + 0];
+    uint64_t first = kmers[heads[nd]];
+    for (uint32_t b = 0; b < KMER; ++b) put_base(pos++, (first >> (2 * (KMER - 1 - b))) & 3);
+    for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put_base(pos++, kmers[c] & 3);
+  }
+  // 5. edges
+  for (size_t nd = 0; nd < n_nodes; ++nd) {
+    uint32_t e = out.node_hdr[nd * 4 + 3];
+    uint64_t firstk = kmers[heads[nd]], lastk = kmers[tail[nd]];
+    for (uint32_t b = 0; b < 4; ++b) {
+      if ((e >> 4) & (1u << b)) {
+        size_t j = find(((lastk << 2) | b) & KMER_MASK);
+        if (kmer_off[j] != 0) throw std::runtime_error("index build: right edge does not land on a unitig start");
+        out.node_redge[nd * 4 + b] = kmer_node[j];
+      }
+      if (e & (1u << b)) {
+        size_t j = find(((uint64_t)b << (2 * (KMER - 1))) | (firstk >> 2));
+        if (j != tail[kmer_node[j]]) throw std::runtime_error("index build: left edge does not land on a unitig end");
+        out.node_ledge[nd * 4 + b] = kmer_node[j];
+      }
+    }
+  }
+  // 6. dictionary, load factor <= 0.5
+  uint64_t slots = 64;
+  while (slots < 2 * (uint64_t)n + 2) slots <<= 1;
+  out.ht_slots = slots;
+  out.ht.assign(slots * 2, 0);
+  for (uint64_t s = 0; s < slots; ++s) out.ht[2 * s] = HT_EMPTY;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t h = mix64(kmers[i]) & (slots - 1);
+    while (out.ht[2 * h] != HT_EMPTY) h = (h + 1) & (slots - 1);
+    out.ht[2 * h] = kmers[i];
+    out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
+  }
+}
+
+}  // namespace nimble

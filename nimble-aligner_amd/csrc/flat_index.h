@@ -1,0 +1,72 @@
+// flat_index.h -- host-side builder of the device-resident index (flat arrays, no pointers).
+//
+// Replaces debruijn_mapping::build_index::<Kmer30> (call sites src/bin/main.rs:121-128,
+// tests/utils.rs:48-51, src/align.rs:1007-1012 of the reference): a stranded, coloured, compacted
+// de Bruijn graph over all 30-mers of the library rows plus an exact k-mer dictionary.  The layout is
+// designed for the gfx950 walk kernel: 16-byte hash slots, 16-byte node records, 2-bit packed
+// unitigs, CSR colour classes.  Built once per library on the host (the reference does the same on
+// the CPU with `num_cores` threads); it is not on the per-read path.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace nimble {
+
+constexpr uint32_t KMER = 30;
+constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
+constexpr uint64_t HT_EMPTY = ~0ULL;
+
+// shared by host build and device kernels ----------------------------------------------------
+#if defined(__HIPCC__)
+#define NIMBLE_HD __host__ __device__ inline
+#else
+#define NIMBLE_HD inline
+#endif
+
+NIMBLE_HD uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+// content hash of an equivalence class (ascending ids); streaming form
+NIMBLE_HD uint64_t class_hash_init() { return 0x9E3779B97F4A7C15ULL; }
+NIMBLE_HD uint64_t class_hash_step(uint64_t h, uint32_t id) {
+  h = (h ^ (uint64_t)id) * 0xff51afd7ed558ccdULL;
+  return h ^ (h >> 29);
+}
+NIMBLE_HD uint64_t class_hash_final(uint64_t h, uint32_t len) { return mix64(h ^ ((uint64_t)len * 0x9FB21C651E98DF25ULL)); }
+// DnaString::from_acgt_bytes: A/a C/c G/g T/t -> 0..3, everything else -> 0
+NIMBLE_HD uint32_t encode_base(uint32_t c) {
+  uint32_t l = c | 0x20u;
+  uint32_t v = (l >> 1) & 3u;  // a->0 c->1 g->3 t->2
+  v ^= v >> 1;                 // a->0 c->1 g->2 t->3
+  bool ok = (l == 'a') | (l == 'c') | (l == 'g') | (l == 't');
+  return ok ? v : 0u;
+}
+
+// intern table slot: high 32 bits = tag (never 0), low 32 bits = class id or INTERN_PENDING
+constexpr uint32_t INTERN_PENDING = 0xFFFFFFFFu;
+NIMBLE_HD uint32_t intern_tag(uint64_t h) { return (uint32_t)(h >> 32) | 1u; }
+
+struct FlatIndex {
+  // exact dictionary k-mer -> (node, offset): slot = {key, node<<32 | offset}; linear probing
+  std::vector<uint64_t> ht;  // 2 x u64 per slot
+  uint64_t ht_slots = 0;     // power of two
+  // node record: {seq_start (base offset into unitig), len (bases), colour, exts (lext | rext<<4)}
+  std::vector<uint32_t> node_hdr;    // 4 x u32 per node
+  std::vector<uint32_t> node_redge;  // 4 x u32 per node, target node per base
+  std::vector<uint32_t> node_ledge;  // 4 x u32 per node
+  std::vector<uint64_t> unitig;      // 2-bit packed, base i at word i>>5, bits 62-2*(i&31)
+  std::vector<uint32_t> col_off;     // CSR over static classes, n_colours+1
+  std::vector<uint32_t> col_ids;
+  uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
+};
+
+// seqs: concatenated ASCII, off[n+1].  Throws std::runtime_error on inconsistency.
+void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs, FlatIndex &out);
+
+}  // namespace nimble

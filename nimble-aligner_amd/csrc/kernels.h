@@ -1,0 +1,90 @@
+// kernels.h -- launch interface between the C ABI (capi.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "../../include/nimble_hip.h"
+
+namespace nimble {
+
+constexpr uint32_t CLS_NONE = 0xFFFFFFFFu;     // NIMBLE_CLASS_NONE
+constexpr uint32_t CLS_PENDING = 0xFFFFFFFEu;  // passing alignment whose class awaits interning
+constexpr uint32_t SLOT_NONE = 0xFFFFFFFFu;
+constexpr uint64_t HIST_EMPTY = ~0ULL;
+constexpr uint32_t R_TODO = 255;  // prefilter verdict "go on to the walk"
+
+// device view of the index (all pointers are device memory)
+struct DevIndex {
+  const uint4 *ht;          // {key lo, key hi, offset, node}
+  uint64_t ht_mask;
+  const uint4 *node_hdr;    // {seq_start, len, colour, exts}
+  const uint4 *node_redge;  // target node per base
+  const uint4 *node_ledge;
+  const uint64_t *unitig;
+  // class table: static colour classes first, device-interned intersections appended
+  uint32_t *cls_off;
+  uint32_t *cls_len;
+  uint32_t *cls_ids;
+  uint32_t n_static;
+  uint32_t cls_cap;       // capacity in classes
+  uint32_t ids_cap;       // capacity of cls_ids
+  uint64_t *intern;       // {tag<<32 | class id}, 0 = empty
+  uint64_t intern_mask;
+  uint32_t *dyn_state;    // [0]=next class id [1]=next free id slot in cls_ids [2]=overflow flag
+};
+
+// per-call device arrays (SoA, stride = n)
+struct CallBuffers {
+  uint64_t n;
+  uint32_t key_words;   // words per packed key (R1 ++ R2)
+  uint32_t paired;
+  uint64_t *keys;       // [key_words][n]
+  uint32_t *len[2];     // bases per mate
+  uint64_t *key_hash;   // hash of (total length, packed words)
+  uint8_t *pre[2];      // prefilter verdict per mate: ShortRead / HighEntropy / R_TODO
+  uint8_t *reason[2];
+  uint32_t *score[2];
+  uint32_t *mism[2];
+  uint32_t *cls[2];
+  uint32_t *dyn_off[2];   // offset of the pending class in scratch
+  uint32_t *dyn_len[2];
+  uint64_t *dyn_hash[2];
+  uint32_t *dyn_pos[2];   // intern slot claimed / matched in the last round
+  uint32_t *slot;         // dedup slot per read or SLOT_NONE
+  uint8_t *counted;
+  uint32_t *scratch;      // pending class ids of this call
+  uint32_t scratch_cap;
+  uint32_t *ws_cols;      // overflow of the per-lane visited-colour list: [rows][lanes]
+  uint32_t ws_rows;
+  uint32_t ws_lanes;
+  uint64_t *dedup;        // {tag<<32 | read index}, 0 = empty
+  uint64_t dedup_mask;
+  uint64_t *hist_keys;    // (cls1 << 32 | cls2), HIST_EMPTY = empty
+  uint64_t *hist_cnt;
+  uint64_t hist_mask;
+  // [0..7] = counters of nimble_call_counters, [8]=scratch used [9]=unresolved interns
+  // [10]=error flags [11]=histogram entries (compaction)
+  uint64_t *state;
+};
+
+enum { ERR_SCRATCH = 1, ERR_CLASS_CAP = 2, ERR_IDS_CAP = 4, ERR_HIST = 8 };
+
+void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const uint8_t *r2, const uint64_t *off2,
+                 uint32_t fixed_len, uint32_t max_len, uint32_t min_len, const double *plog, uint32_t plog_max_len,
+                 const CallBuffers &cb);
+void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters);
+void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
+void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
+void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb);
+void launch_count(hipStream_t s, const CallBuffers &cb);
+void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt,
+                         uint64_t cap);
+void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes);
+void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
+
+uint32_t align_ws_lanes();   // lanes of the align grid (sizes ws_cols)
+uint32_t align_lds_cols();   // visited colours kept in LDS before spilling to ws_cols
+
+}  // namespace nimble

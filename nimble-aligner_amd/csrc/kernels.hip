@@ -1,0 +1,748 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the nimble hot path.
+//
+// Integer / bit work throughout; no MFMA.  What is mirrored from the reference:
+//   k_pack          DnaString::from_acgt_bytes (src/parse/fastq.rs:36), the read_key of
+//                   src/align.rs:576-579 (R1 bases ++ R2 bases), the length and entropy prefilters of
+//                   pseudoalign (src/align.rs:955-962) with utils::shannon_entropy (src/utils.rs:96-119)
+//   k_align         Pseudoaligner::map_read_with_mismatch (external crate, call site src/align.rs:965),
+//                   the rest of pseudoalign (src/align.rs:966-988) and filter_alignment_by_metrics
+//                   (src/filter/align.rs:4-45)
+//   k_intern_*      gives every intersected class a canonical id (content-addressed), the device form of
+//                   "the equivalence class" the reference carries around as Vec<u32>
+//   k_dedup/k_count score_map keyed by the read string (src/align.rs:496-505,685), require_valid_pair /
+//                   filter_pair (src/align.rs:582-588,732-760) and the per-key `+= 1` of src/align.rs:245-249,
+//                   grouped by (class R1, class R2)
+//
+// Layout rules used here: one lane per read(-pair); 64-wide waves; packed keys are stored word-major
+// ([word][read]) so every per-read load/store of a wave is one contiguous 512-byte segment; ASCII input is
+// staged through LDS with 16-byte coalesced loads; the walk keeps the lane's packed read in an LDS column
+// (dynamic indexing without scratch) and only gathers 16-byte hash slots / node records / 8-byte unitig
+// words from the (L2 / Infinity-Cache resident) index.
+#include <hip/hip_runtime.h>
+
+#include "flat_index.h"
+#include "kernels.h"
+
+namespace nimble {
+
+namespace {
+
+constexpr int PACK_BLOCK = 256;
+constexpr int ALIGN_BLOCK = 256;
+constexpr int ALIGN_GRID = 2048;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
+constexpr int LDS_COLS = 6;
+constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack: ASCII -> 2-bit packed key, lengths, key hash, prefilter verdicts
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__ r1, const uint64_t *__restrict__ off1,
+                                                     const uint8_t *__restrict__ r2, const uint64_t *__restrict__ off2,
+                                                     uint32_t fixed_len, uint32_t rpb, uint32_t tile_bytes,
+                                                     uint32_t min_len, const double *__restrict__ plog,
+                                                     CallBuffers cb) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n = cb.n;
+  const uint64_t r0 = (uint64_t)blockIdx.x * rpb;
+  if (r0 >= n) return;
+  const uint32_t cnt = (uint32_t)((n - r0 < rpb) ? (n - r0) : rpb);
+  const int nm = cb.paired ? 2 : 1;
+  uint64_t seg_start[2] = {0, 0};
+  uint32_t shift[2] = {0, 0};
+  for (int m = 0; m < nm; ++m) {
+    const uint8_t *src = m ? r2 : r1;
+    const uint64_t *off = m ? off2 : off1;
+    uint64_t s = off ? off[r0] : r0 * fixed_len;
+    uint64_t e = off ? off[r0 + cnt] : (r0 + cnt) * fixed_len;
+    uintptr_t a = (uintptr_t)(src + s);
+    uintptr_t a0 = a & ~(uintptr_t)15;
+    shift[m] = (uint32_t)(a - a0);
+    seg_start[m] = s;
+    uint32_t nvec = (uint32_t)((e - s + shift[m] + 15) >> 4);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds + (size_t)m * tile_bytes);
+    const uint4 *g = reinterpret_cast<const uint4 *>(a0);
+    for (uint32_t i = tid; i < nvec; i += PACK_BLOCK) dst[i] = g[i];  // 16 B / lane, coalesced
+  }
+  __syncthreads();
+  if (tid >= cnt) return;
+  const uint64_t r = r0 + tid;
+  uint32_t L[2] = {0, 0};
+  const uint8_t *p[2] = {nullptr, nullptr};
+  for (int m = 0; m < nm; ++m) {
+    const uint64_t *off = m ? off2 : off1;
+    uint64_t s = off ? off[r] : r * fixed_len;
+    L[m] = off ? (uint32_t)(off[r + 1] - s) : fixed_len;
+    p[m] = lds + (size_t)m * tile_bytes + shift[m] + (uint32_t)(s - seg_start[m]);
+  }
+  const uint32_t total = L[0] + L[1];
+  uint64_t acc = 0, h = 0x8F1BBCDCCA62C1D6ULL ^ (uint64_t)total;
+  uint32_t nb = 0, w = 0;
+  for (int m = 0; m < nm; ++m) {
+    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
+    const uint8_t *q = p[m];
+    for (uint32_t i = 0; i < L[m]; ++i) {
+      uint32_t c = encode_base(q[i]);
+      cA += (c == 0);
+      cC += (c == 1);
+      cG += (c == 2);
+      cT += (c == 3);
+      acc = (acc << 2) | c;
+      if (++nb == 32) {
+        cb.keys[(uint64_t)w * n + r] = acc;
+        h = (h ^ acc) * 0xff51afd7ed558ccdULL;
+        h ^= h >> 32;
+        ++w;
+        nb = 0;
+        acc = 0;
+      }
+    }
+    cb.len[m][r] = L[m];
+    uint8_t verdict = (uint8_t)R_TODO;
+    if (L[m] < min_len) {
+      verdict = NIMBLE_R_SHORT_READ;
+    } else {
+      // shannon_entropy: sum f*log2(f) over A, T, C, G in that order, terms from the host-built table
+      const double *row = plog + ((uint64_t)L[m] * (L[m] + 1)) / 2;
+      double e = 0.0;
+      if (cA) e += row[cA];
+      if (cT) e += row[cT];
+      if (cC) e += row[cC];
+      if (cG) e += row[cG];
+      if (-e < MIN_ENTROPY_SCORE) verdict = NIMBLE_R_HIGH_ENTROPY;
+    }
+    cb.pre[m][r] = verdict;
+  }
+  if (nb) {
+    acc <<= (64 - 2 * nb);
+    cb.keys[(uint64_t)w * n + r] = acc;
+    h = (h ^ acc) * 0xff51afd7ed558ccdULL;
+    h ^= h >> 32;
+  }
+  cb.key_hash[r] = mix64(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_align helpers
+// ---------------------------------------------------------------------------------------------
+struct Lane {
+  const uint64_t *rd;  // LDS column holding the packed key (stride ALIGN_BLOCK words)
+  uint32_t *lc;        // LDS column of visited colours (stride ALIGN_BLOCK)
+  uint32_t *ws;        // global spill column (stride ws_lanes)
+  uint32_t ws_lanes, ws_rows;
+  uint32_t n_cols, last_col, walk_nodes;
+  uint32_t probes, nodes;
+  uint64_t entries;
+  const uint32_t *cls_len;
+  int want_counters;
+  uint32_t overflow;
+};
+
+// nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
+__device__ __forceinline__ uint64_t lds_bits(const uint64_t *rd, uint32_t pos, uint32_t nb) {
+  uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
+  uint64_t hi = rd[w * ALIGN_BLOCK], lo = rd[(w + 1) * ALIGN_BLOCK];
+  uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
+  return x >> (64u - 2u * nb);
+}
+__device__ __forceinline__ uint32_t lds_base(const uint64_t *rd, uint32_t pos) {
+  return (uint32_t)(rd[(pos >> 5) * ALIGN_BLOCK] >> (62u - 2u * (pos & 31u))) & 3u;
+}
+__device__ __forceinline__ uint64_t g_bits(const uint64_t *__restrict__ u, uint64_t pos, uint32_t nb) {
+  uint64_t w = pos >> 5;
+  uint32_t s = (uint32_t)(pos & 31u) * 2u;
+  uint64_t hi = u[w], lo = u[w + 1];
+  uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
+  return x >> (64u - 2u * nb);
+}
+__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t b) {
+  return b == 0 ? v.x : (b == 1 ? v.y : (b == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ bool ht_lookup(const DevIndex &ix, uint64_t km, uint32_t &node, uint32_t &off) {
+  uint64_t h = mix64(km) & ix.ht_mask;
+  for (;;) {
+    uint4 s = ix.ht[h];
+    uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
+    if (key == km) {
+      off = s.z;
+      node = s.w;
+      return true;
+    }
+    if (key == HT_EMPTY) return false;
+    h = (h + 1) & ix.ht_mask;
+  }
+}
+
+// seed search with stride 3 from kmer_pos (positions relative to the mate)
+__device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
+                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off) {
+  while (kmer_pos <= last_kmer_pos) {
+    uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
+    ln.probes++;
+    if (ht_lookup(ix, km, node, off)) return true;
+    kmer_pos += 3;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void push_col(Lane &ln, uint32_t colour) {
+  ln.nodes++;
+  ln.walk_nodes++;
+  if (ln.want_counters) ln.entries += ln.cls_len[colour];
+  if (ln.n_cols && colour == ln.last_col) return;  // intersection is idempotent
+  uint32_t j = ln.n_cols;
+  ln.last_col = colour;
+  if (j < LDS_COLS) {
+    ln.lc[j * ALIGN_BLOCK] = colour;
+  } else if (j - LDS_COLS < ln.ws_rows) {
+    ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes] = colour;
+  } else {
+    ln.overflow = 1;
+    return;
+  }
+  ln.n_cols = j + 1;
+}
+__device__ __forceinline__ uint32_t get_col(const Lane &ln, uint32_t j) {
+  return j < LDS_COLS ? ln.lc[j * ALIGN_BLOCK] : ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes];
+}
+
+// compare n bases forward: key[rpos + i] vs unitig[upos + i].  Returns the bases accepted; a base that
+// takes this node's mismatch count above `allowed` stops the compare and is not accepted.
+__device__ __forceinline__ uint32_t cmp_fwd(const Lane &ln, const uint64_t *__restrict__ unitig, uint32_t rpos,
+                                            uint64_t upos, uint32_t n, uint32_t allowed, uint32_t &mism,
+                                            bool &premature) {
+  uint32_t matched = 0, seen = 0;
+  premature = false;
+  while (matched < n) {
+    uint32_t c = n - matched < 32u ? n - matched : 32u;
+    uint64_t x = lds_bits(ln.rd, rpos + matched, c) ^ g_bits(unitig, upos + matched, c);
+    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
+    uint32_t cnt = (uint32_t)__popcll(m);
+    if (seen + cnt <= allowed) {
+      seen += cnt;
+      mism += cnt;
+      matched += c;
+    } else {
+      uint32_t k = allowed - seen;  // tolerated here; mismatch k+1 breaks
+      for (uint32_t t = 0; t < k; ++t) m &= ~(1ULL << (63 - __clzll((long long)m)));
+      uint32_t bit = 63u - (uint32_t)__clzll((long long)m);
+      matched += c - 1u - (bit >> 1);
+      mism += k + 1;
+      premature = true;
+      break;
+    }
+  }
+  return matched;
+}
+// compare n bases backward: key[rlast - i] vs unitig[ulast - i]
+__device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const uint64_t *__restrict__ unitig, uint32_t rlast,
+                                            uint64_t ulast, uint32_t n, uint32_t allowed, uint32_t &mism,
+                                            bool &premature) {
+  uint32_t matched = 0, seen = 0;
+  premature = false;
+  while (matched < n) {
+    uint32_t c = n - matched < 32u ? n - matched : 32u;
+    uint64_t x = lds_bits(ln.rd, rlast - matched - c + 1u, c) ^ g_bits(unitig, ulast - matched - c + 1u, c);
+    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
+    uint32_t cnt = (uint32_t)__popcll(m);
+    if (seen + cnt <= allowed) {
+      seen += cnt;
+      mism += cnt;
+      matched += c;
+    } else {
+      uint32_t k = allowed - seen;
+      for (uint32_t t = 0; t < k; ++t) m &= m - 1;
+      uint32_t bit = (uint32_t)__ffsll((long long)m) - 1u;
+      matched += bit >> 1;
+      mism += k + 1;
+      premature = true;
+      break;
+    }
+  }
+  return matched;
+}
+
+// map_read_to_nodes_with_mismatch for the mate occupying key bases [base0, base0 + L)
+__device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed, uint32_t &coverage,
+                     uint32_t &mismatches) {
+  ln.n_cols = 0;
+  ln.walk_nodes = 0;
+  if (L < KMER) return false;
+  uint32_t cov = 0, mm = 0;
+  const uint32_t left_thr = (uint32_t)(0.2 * (double)L);
+  uint32_t kmer_pos = 0;
+  const uint32_t last_kmer_pos = L - KMER;
+  uint32_t node = 0, koff = 0;
+  bool have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff);
+
+  if (have && kmer_pos >= left_thr) {  // left extension
+    uint32_t last_pos = kmer_pos - 1;
+    uint32_t pnode = node;
+    uint32_t poff = koff > 0 ? koff - 1 : 0;
+    for (;;) {
+      uint4 hdr = ix.node_hdr[pnode];
+      uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
+      bool prem;
+      uint32_t matched = cmp_bwd(ln, ix.unitig, base0 + last_pos, (uint64_t)hdr.x + poff, n, allowed, mm, prem);
+      cov += matched;
+      if (last_pos + 1 - matched == 0 || prem) break;
+      last_pos -= matched;
+      uint32_t nbase = lds_base(ln.rd, base0 + last_pos);
+      if (hdr.w & (1u << nbase)) {
+        uint4 le = ix.node_ledge[pnode];
+        pnode = sel4(le, nbase);
+        uint4 h2 = ix.node_hdr[pnode];
+        poff = h2.y - KMER;
+        push_col(ln, h2.z);
+      } else {
+        break;
+      }
+    }
+  }
+  if (kmer_pos <= last_kmer_pos) {  // forward search (a seed was found)
+    for (;;) {
+      uint4 hdr = ix.node_hdr[node];
+      kmer_pos += KMER;
+      cov += KMER;
+      push_col(ln, hdr.z);
+      uint32_t remaining = L - kmer_pos;
+      uint32_t ref_off = koff + KMER;
+      uint32_t informative = hdr.y - ref_off;
+      uint32_t n = remaining < informative ? remaining : informative;
+      bool prem = false;
+      uint32_t matched = 0;
+      if (n) matched = cmp_fwd(ln, ix.unitig, base0 + kmer_pos, (uint64_t)hdr.x + ref_off, n, allowed, mm, prem);
+      cov += matched;
+      kmer_pos += matched;
+      if (kmer_pos >= L) break;
+      uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
+      if (!prem && ((hdr.w >> 4) & (1u << nbase))) {
+        uint4 re = ix.node_redge[node];
+        node = sel4(re, nbase);
+        koff = 0;
+        kmer_pos -= KMER - 1;
+        cov -= KMER - 1;
+      } else {
+        if (kmer_pos > last_kmer_pos) break;
+        if (!find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff)) break;
+      }
+    }
+  }
+  if (ln.walk_nodes == 0) return false;
+  coverage = cov;
+  mismatches = mm;
+  return true;
+}
+
+__device__ __forceinline__ bool class_contains(const uint32_t *__restrict__ ids, uint32_t len, uint32_t id) {
+  uint32_t lo = 0, hi = len;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    uint32_t v = ids[mid];
+    if (v < id) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo < len && ids[lo] == id;
+}
+
+// nodes_to_eq_class: intersection of the visited colours, smallest class first.
+// Returns the class length; writes ids to `out` when non-null.
+__device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t &best_col, uint32_t &best_len,
+                                   uint64_t &hash, uint32_t *out) {
+  uint32_t best = get_col(ln, 0);
+  uint32_t bl = ix.cls_len[best];
+  for (uint32_t j = 1; j < ln.n_cols; ++j) {
+    uint32_t c = get_col(ln, j);
+    uint32_t l = ix.cls_len[c];
+    if (l < bl) { best = c; bl = l; }
+  }
+  best_col = best;
+  best_len = bl;
+  const uint32_t *bids = ix.cls_ids + ix.cls_off[best];
+  uint32_t count = 0;
+  uint64_t h = class_hash_init();
+  for (uint32_t t = 0; t < bl; ++t) {
+    uint32_t id = bids[t];
+    bool ok = true;
+    for (uint32_t j = 0; j < ln.n_cols; ++j) {
+      uint32_t c = get_col(ln, j);
+      if (c == best) continue;
+      if (!class_contains(ix.cls_ids + ix.cls_off[c], ix.cls_len[c], id)) { ok = false; break; }
+    }
+    if (ok) {
+      if (out) out[count] = id;
+      h = class_hash_step(h, id);
+      ++count;
+    }
+  }
+  hash = class_hash_final(h, count);
+  return count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_align: walk + class + thresholds, one lane per read(-pair), persistent grid-stride blocks
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align_params p, CallBuffers cb,
+                                                       int want_counters) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t kw = cb.key_words;
+  uint64_t *col = lds64 + tid;
+  Lane ln;
+  ln.rd = col;
+  ln.lc = reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) + tid;
+  ln.ws_lanes = cb.ws_lanes;
+  ln.ws_rows = cb.ws_rows;
+  ln.ws = cb.ws_cols + ((uint64_t)blockIdx.x * ALIGN_BLOCK + tid);
+  ln.cls_len = ix.cls_len;
+  ln.want_counters = want_counters;
+  ln.probes = ln.nodes = 0;
+  ln.entries = 0;
+  ln.overflow = 0;
+  ln.n_cols = ln.last_col = ln.walk_nodes = 0;
+  uint32_t c_seeded = 0, c_pre = 0;
+  const uint64_t n = cb.n;
+  const int nm = cb.paired ? 2 : 1;
+  const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t r = tile * ALIGN_BLOCK + tid;
+    const bool active = r < n;
+    uint32_t L[2] = {0, 0};
+    if (active) {
+      L[0] = cb.len[0][r];
+      if (nm == 2) L[1] = cb.len[1][r];
+      uint32_t nw = (L[0] + L[1] + 31u) >> 5;
+      for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? cb.keys[(uint64_t)w * n + r] : 0ULL;
+      col[kw * ALIGN_BLOCK] = 0ULL;
+    }
+    bool any_walk = false;
+    for (int m = 0; m < nm; ++m) {
+      uint32_t reason = NIMBLE_R_NONE, score = 0, mm = 0, cls = CLS_NONE;
+      uint32_t need = 0, best_col = 0, best_len = 0;
+      uint64_t dhash = 0;
+      if (active) {
+        uint32_t pre = cb.pre[m][r];
+        if (pre != R_TODO) {
+          reason = pre;
+          if (m == 0) c_pre++;
+        } else {
+          uint32_t cov = 0, mis = 0;
+          bool some = walk(ix, ln, m ? L[0] : 0u, L[m], p.num_mismatches, cov, mis);
+          if (!some) {
+            reason = NIMBLE_R_NO_MATCH;
+          } else {
+            any_walk = true;
+            score = cov;
+            mm = mis;
+            uint32_t count;
+            if (ln.n_cols == 1) {
+              best_col = get_col(ln, 0);
+              best_len = count = ix.cls_len[best_col];
+            } else {
+              count = intersect_cols(ix, ln, best_col, best_len, dhash, nullptr);
+            }
+            double normalized = (double)cov / (double)L[m];
+            if (p.discard_nonzero_mismatch && mis != 0) {
+              reason = NIMBLE_R_DISCARDED_NONZERO_MISMATCH;
+            } else if ((uint64_t)cov >= p.score_threshold && normalized >= p.score_percent && count != 0) {
+              if (p.discard_multiple_matches && count > 1) reason = NIMBLE_R_DISCARDED_MULTIPLE_MATCH;
+              else if (mis > p.num_mismatches) reason = NIMBLE_R_ABOVE_MISMATCH_THRESHOLD;
+              else {
+                reason = NIMBLE_R_SUCCESSFUL_MATCH;
+                if (count == best_len) cls = best_col;  // the intersection is the smallest colour itself
+                else { cls = CLS_PENDING; need = count; }
+              }
+            } else {
+              reason = NIMBLE_R_SCORE_BELOW_THRESHOLD;
+            }
+          }
+        }
+      }
+      // wave-aggregated allocation of scratch space for classes that need interning (convergent point)
+      uint32_t total;
+      uint32_t ofs = wave_excl_scan(need, total);
+      unsigned long long base = 0;
+      if (total) {
+        if ((tid & 63u) == 0) base = atomicAdd((unsigned long long *)&cb.state[8], (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+      }
+      if (need) {
+        if (base + ofs + need <= (unsigned long long)cb.scratch_cap) {
+          uint32_t bc, bl;
+          uint64_t hh;
+          intersect_cols(ix, ln, bc, bl, hh, cb.scratch + base + ofs);
+          cb.dyn_off[m][r] = (uint32_t)base + ofs;
+          cb.dyn_len[m][r] = need;
+          cb.dyn_hash[m][r] = dhash;
+        } else {
+          atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_SCRATCH);
+          cls = CLS_NONE;
+        }
+      }
+      if (active) {
+        cb.reason[m][r] = (uint8_t)reason;
+        cb.score[m][r] = score;
+        cb.mism[m][r] = mm;
+        cb.cls[m][r] = cls;
+      }
+    }
+    if (any_walk) c_seeded++;
+  }
+  if (ln.overflow) atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_SCRATCH);
+  if (want_counters) {
+    uint64_t v2 = wave_sum64(ln.probes), v3 = wave_sum64(ln.nodes), v4 = wave_sum64(ln.entries);
+    uint64_t v5 = wave_sum64(c_seeded), v6 = wave_sum64(c_pre);
+    if ((tid & 63u) == 0) {
+      atomicAdd((unsigned long long *)&cb.state[2], (unsigned long long)v2);
+      atomicAdd((unsigned long long *)&cb.state[3], (unsigned long long)v3);
+      atomicAdd((unsigned long long *)&cb.state[4], (unsigned long long)v4);
+      atomicAdd((unsigned long long *)&cb.state[5], (unsigned long long)v5);
+      atomicAdd((unsigned long long *)&cb.state[6], (unsigned long long)v6);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// class interning: content-addressed table {tag | class id}; claims and verification are split by a
+// kernel boundary so that no lane ever waits on another lane.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t n = cb.n;
+  const int m = (int)blockIdx.y;
+  if (i >= n) return;
+  if (cb.cls[m][i] != CLS_PENDING) return;
+  const uint64_t h = cb.dyn_hash[m][i];
+  const uint32_t tag = intern_tag(h);
+  uint64_t pos = round == 0 ? (h & ix.intern_mask) : (((uint64_t)cb.dyn_pos[m][i] + 1) & ix.intern_mask);
+  for (;;) {
+    uint64_t cur = atomicCAS((unsigned long long *)&ix.intern[pos], 0ULL,
+                             ((unsigned long long)tag << 32) | INTERN_PENDING);
+    if (cur == 0) {
+      // this lane owns the slot: append the class to the table and publish its id
+      const uint32_t len = cb.dyn_len[m][i];
+      uint32_t id = atomicAdd(&ix.dyn_state[0], 1u);
+      uint32_t off = atomicAdd(&ix.dyn_state[1], len);
+      if (id >= ix.cls_cap || (uint64_t)off + len > ix.ids_cap) {
+        atomicOr((unsigned long long *)&cb.state[10],
+                 (unsigned long long)(id >= ix.cls_cap ? ERR_CLASS_CAP : ERR_IDS_CAP));
+        ix.intern[pos] = ((uint64_t)tag << 32) | 0u;  // keep the table consistent; the call reports the error
+        cb.dyn_pos[m][i] = (uint32_t)pos;
+        return;
+      }
+      const uint32_t *src = cb.scratch + cb.dyn_off[m][i];
+      for (uint32_t t = 0; t < len; ++t) ix.cls_ids[off + t] = src[t];
+      ix.cls_off[id] = off;
+      ix.cls_len[id] = len;
+      ix.intern[pos] = ((uint64_t)tag << 32) | id;
+      cb.dyn_pos[m][i] = (uint32_t)pos;
+      return;
+    }
+    if ((uint32_t)(cur >> 32) == tag) {  // candidate; content is checked after the kernel boundary
+      cb.dyn_pos[m][i] = (uint32_t)pos;
+      return;
+    }
+    pos = (pos + 1) & ix.intern_mask;
+  }
+}
+
+__global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = (int)blockIdx.y;
+  if (i >= cb.n) return;
+  if (cb.cls[m][i] != CLS_PENDING) return;
+  const uint32_t id = (uint32_t)ix.intern[cb.dyn_pos[m][i]];
+  const uint32_t len = cb.dyn_len[m][i];
+  bool same = id < ix.cls_cap && ix.cls_len[id] == len;
+  if (same) {
+    const uint32_t *a = cb.scratch + cb.dyn_off[m][i];
+    const uint32_t *b = ix.cls_ids + ix.cls_off[id];
+    for (uint32_t t = 0; t < len; ++t)
+      if (a[t] != b[t]) { same = false; break; }
+  }
+  if (same) cb.cls[m][i] = id;
+  else atomicAdd((unsigned long long *)&cb.state[9], 1ULL);  // tag collision: next round probes further
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dedup: pair filter + insert of the read key into the call's dedup table (last writer wins)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t n = cb.n;
+  if (i >= n) return;
+  uint32_t c1 = cb.cls[0][i];
+  uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
+  cb.counted[i] = 0;
+  if (cb.paired && p.require_valid_pair) {
+    // filter_pair: keep only when both classes are non-empty and identical (ids are canonical)
+    if (!(c1 != CLS_NONE && c2 != CLS_NONE && c1 == c2)) {
+      cb.reason[0][i] = NIMBLE_R_NOT_MATCHING_PAIR;
+      cb.reason[1][i] = NIMBLE_R_NOT_MATCHING_PAIR;
+      cb.slot[i] = SLOT_NONE;
+      return;
+    }
+  }
+  if (c1 == CLS_NONE && c2 == CLS_NONE) {
+    cb.slot[i] = SLOT_NONE;
+    return;
+  }
+  const uint64_t h = cb.key_hash[i];
+  const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+  const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)i;
+  const uint32_t total = cb.len[0][i] + (cb.paired ? cb.len[1][i] : 0u);
+  const uint32_t nw = (total + 31u) >> 5;
+  uint64_t pos = h & cb.dedup_mask;
+  for (;;) {
+    uint64_t cur = atomicCAS((unsigned long long *)&cb.dedup[pos], 0ULL, (unsigned long long)mine);
+    if (cur == 0) break;
+    if ((uint32_t)(cur >> 32) == tag) {
+      const uint64_t j = (uint32_t)cur;
+      bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total;
+      for (uint32_t w = 0; same && w < nw; ++w) same = cb.keys[(uint64_t)w * n + i] == cb.keys[(uint64_t)w * n + j];
+      if (same) {
+        atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
+        break;
+      }
+    }
+    pos = (pos + 1) & cb.dedup_mask;
+  }
+  cb.slot[i] = (uint32_t)pos;
+}
+
+// k_count: the representative of each key adds one to the (class R1, class R2) histogram
+__global__ void k_count(CallBuffers cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cb.n) return;
+  const uint32_t s = cb.slot[i];
+  if (s == SLOT_NONE) return;
+  if ((uint32_t)cb.dedup[s] != (uint32_t)i) return;
+  cb.counted[i] = 1;
+  const uint32_t c1 = cb.cls[0][i];
+  const uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
+  const uint64_t key = ((uint64_t)c1 << 32) | c2;
+  uint64_t pos = mix64(key) & cb.hist_mask;
+  for (uint64_t probes = 0; probes <= cb.hist_mask; ++probes) {
+    uint64_t cur = atomicCAS((unsigned long long *)&cb.hist_keys[pos], (unsigned long long)HIST_EMPTY,
+                             (unsigned long long)key);
+    if (cur == HIST_EMPTY || cur == key) {
+      atomicAdd((unsigned long long *)&cb.hist_cnt[pos], 1ULL);
+      return;
+    }
+    pos = (pos + 1) & cb.hist_mask;
+  }
+  atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_HIST);
+}
+
+__global__ void k_hist_compact(CallBuffers cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt, uint64_t cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > cb.hist_mask) return;
+  const uint64_t key = cb.hist_keys[i];
+  if (key == HIST_EMPTY) return;
+  uint64_t o = atomicAdd((unsigned long long *)&cb.state[11], 1ULL);
+  if (o < cap) {
+    c1[o] = (uint32_t)(key >> 32);
+    c2[o] = (uint32_t)key;
+    cnt[o] = cb.hist_cnt[i];
+  }
+}
+
+__global__ void k_hist_dense_se(CallBuffers cb, int64_t *counts, uint32_t n_classes) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > cb.hist_mask) return;
+  const uint64_t key = cb.hist_keys[i];
+  if (key == HIST_EMPTY) return;
+  const uint32_t c1 = (uint32_t)(key >> 32), c2 = (uint32_t)key;
+  if (c2 == CLS_NONE && c1 < n_classes) counts[c1] = (int64_t)cb.hist_cnt[i];
+}
+
+__global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+inline uint32_t blocks_for(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
+
+}  // namespace
+
+uint32_t align_ws_lanes() { return (uint32_t)ALIGN_GRID * ALIGN_BLOCK; }
+uint32_t align_lds_cols() { return LDS_COLS; }
+
+void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const uint8_t *r2, const uint64_t *off2,
+                 uint32_t fixed_len, uint32_t max_len, uint32_t min_len, const double *plog, uint32_t plog_max_len,
+                 const CallBuffers &cb) {
+  (void)plog_max_len;
+  if (cb.n == 0) return;
+  // reads per block: as many as fit a 64 KiB LDS budget (both mates), at most one per lane
+  const uint32_t budget = 64 * 1024;
+  const uint32_t nm = cb.paired ? 2 : 1;
+  uint32_t rpb = PACK_BLOCK;
+  while (rpb > 1 && (uint64_t)nm * ((uint64_t)rpb * max_len + 48) > budget) rpb >>= 1;
+  uint32_t tile_bytes = (uint32_t)((((uint64_t)rpb * max_len + 32) + 15) & ~15ULL);
+  uint32_t grid = blocks_for(cb.n, rpb);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(PACK_BLOCK), nm * tile_bytes, s, r1, off1, r2, off2, fixed_len, rpb,
+                     tile_bytes, min_len, plog, cb);
+}
+
+void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters) {
+  if (cb.n == 0) return;
+  uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  uint32_t grid = (uint32_t)(tiles < (uint64_t)ALIGN_GRID ? tiles : (uint64_t)ALIGN_GRID);
+  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4;
+  hipLaunchKernelGGL(k_align, dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb, want_counters);
+}
+
+void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_intern_claim, dim3(blocks_for(cb.n, 256), cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb, round);
+}
+void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_intern_verify, dim3(blocks_for(cb.n, 256), cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb);
+}
+void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_dedup, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, p, cb);
+}
+void launch_count(hipStream_t s, const CallBuffers &cb) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_count, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, cb);
+}
+void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt,
+                         uint64_t cap) {
+  hipLaunchKernelGGL(k_hist_compact, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, c1, c2, cnt, cap);
+}
+void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes) {
+  hipLaunchKernelGGL(k_hist_dense_se, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, counts,
+                     n_classes);
+}
+void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n) {
+  if (n == 0) return;
+  uint32_t grid = blocks_for(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace nimble

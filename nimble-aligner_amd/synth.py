@@ -1,0 +1,171 @@
+"""Synthetic libraries and read sets for the configs of BASELINE.json.
+
+Deterministic for a given (T, n, seed).  numpy implementation for tests and CPU-side use; bench.py has
+the same recipe written with torch ops so that 10 M reads are generated directly in HBM.
+
+Library: allele families of 4 (mirrors tests/test-sequences/libraries/basic.json A02-0/1/2/LC): T/4 roots,
+i.i.d. uniform ACGT, length uniform in [600, 2400]; alleles 2-4 = root with substitutions at rate 1 %;
+allele 4 is a case-flipped copy of allele 1 in 25 % of the families (duplicate-sequence classes).
+Reads (L = 150): 75 % on-target (uniform feature, uniform start, 50 % reverse-complemented, 0.5 %
+substitutions), 15 % uniform random, 5 % exact duplicates of an earlier read, 3 % low-complexity
+(140 x A + 10 random), 2 % on-target with 1-3 bases overwritten by N.
+"""
+import json
+
+import numpy as np
+
+LIB_SEED = 0x6E696D626C65  # "nimble"
+READ_SEED = 0x52454144     # "READ"
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def make_library(T, seed=LIB_SEED):
+    """Returns (names, sequences) of the T features (strings; some lower-case)."""
+    assert T % 4 == 0
+    rng = np.random.default_rng(seed + T)
+    names, seqs = [], []
+    for fam in range(T // 4):
+        length = int(rng.integers(600, 2401))
+        root = rng.integers(0, 4, size=length, dtype=np.uint8)
+        alleles = [root]
+        for _ in range(3):
+            a = root.copy()
+            mask = rng.random(length) < 0.01
+            a[mask] = (a[mask] + rng.integers(1, 4, size=int(mask.sum()), dtype=np.uint8)) % 4
+            alleles.append(a)
+        flip = rng.random() < 0.25
+        for k, a in enumerate(alleles):
+            s = ACGT[a].tobytes().decode()
+            if k == 3 and flip:
+                s = ACGT[alleles[0]].tobytes().decode().lower()
+            names.append("F%05d-%d" % (fam, k))
+            seqs.append(s)
+    return names, seqs
+
+
+def library_json(names, seqs, cfg=None):
+    """The [config, {headers, columns}] object of a library file (reference_library.rs:28-78)."""
+    config = dict(score_percent=0.33, score_filter=25, score_threshold=50, num_mismatches=0,
+                  discard_multiple_matches=False, require_valid_pair=False, discard_multi_hits=0, intersect_level=0,
+                  max_hits_to_report=10, group_on="", trim_target_length=40, trim_strictness=0.9, data_type="DNA")
+    if cfg:
+        config.update(cfg)
+    body = dict(headers=["reference_genome", "sequence_name", "nt_length", "sequence"],
+                columns=[["synthetic"] * len(names), list(names), [str(len(s)) for s in seqs], list(seqs)])
+    return [config, body]
+
+
+def write_library(path, names, seqs, cfg=None):
+    with open(path, "w") as f:
+        json.dump(library_json(names, seqs, cfg), f)
+
+
+def expand_rows(names, seqs):
+    """Row expansion of reference_library::get_reference_library (reference_library.rs:128-161): per
+    feature the row itself, then name + '§rev' with the reverse-complemented sequence (U->T, N kept)."""
+    comp = {"a": "t", "c": "g", "t": "a", "g": "c", "u": "a", "A": "T", "C": "G", "T": "A", "G": "C", "U": "A"}
+    out_names, out_seqs = [], []
+    for nme, s in zip(names, seqs):
+        s = s.replace("U", "T").replace("u", "t")
+        out_names += [nme, nme + "§rev"]
+        out_seqs += [s, "".join(comp.get(ch, "N") for ch in reversed(s))]
+    return out_names, out_seqs
+
+
+def _codes(seqs):
+    lut = np.zeros(256, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+        lut[ch + 32] = i
+    cat = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return lut[cat], off
+
+
+def make_reads(seqs, n, L=150, seed=READ_SEED, paired=False, chunk=1 << 20):
+    """Returns uint8 ASCII array [n, L] (and a second one for the mates when paired)."""
+    rng = np.random.default_rng(seed + n)
+    cat, off = _codes(seqs)
+    lens = np.diff(off)
+    T = len(seqs)
+    r1 = np.empty((n, L), dtype=np.uint8)
+    r2 = np.empty((n, L), dtype=np.uint8) if paired else None
+    kind = rng.random(n)
+    # thresholds: on-target 0.75 | off-target 0.15 | duplicate 0.05 | low complexity 0.03 | N reads 0.02
+    K_ON, K_OFF, K_DUP, K_LOW = 0.75, 0.90, 0.95, 0.98
+    ar = np.arange(L, dtype=np.int64)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        m = hi - lo
+        k = kind[lo:hi]
+        f = rng.integers(0, T, size=m)
+        flen = lens[f]
+        strand = rng.random(m) < 0.5
+        if not paired:
+            start = (rng.random(m) * (flen - L + 1)).astype(np.int64)
+            codes = cat[(off[f] + start)[:, None] + ar]
+            rc = COMP[codes[:, ::-1]]
+            codes = np.where(strand[:, None], rc, codes)
+            mates = None
+        else:
+            frag = np.clip(np.rint(rng.normal(350.0, 50.0, size=m)).astype(np.int64), L, flen)
+            start = (rng.random(m) * (flen - frag + 1)).astype(np.int64)
+            head = cat[(off[f] + start)[:, None] + ar]                      # fragment[0:L]
+            tail = cat[(off[f] + start + frag - L)[:, None] + ar]           # fragment[-L:]
+            tail_rc = COMP[tail[:, ::-1]]                                   # revcomp(fragment)[0:L]
+            codes = np.where(strand[:, None], tail_rc, head)
+            mates = np.where(strand[:, None], head, tail_rc)
+
+        def mutate(c):
+            mask = rng.random((m, L)) < 0.005
+            bump = rng.integers(1, 4, size=(m, L), dtype=np.uint8)
+            return np.where(mask, (c + bump) % 4, c).astype(np.uint8)
+
+        codes = mutate(codes)
+        out = ACGT[codes]
+        outm = ACGT[mutate(mates)] if paired else None
+        # off-target
+        sel = (k >= K_ON) & (k < K_OFF)
+        cnt = int(sel.sum())
+        out[sel] = ACGT[rng.integers(0, 4, size=(cnt, L), dtype=np.uint8)]
+        if paired:
+            outm[sel] = ACGT[rng.integers(0, 4, size=(cnt, L), dtype=np.uint8)]
+        # low complexity: 140 x A then 10 random
+        sel = (k >= K_DUP) & (k < K_LOW)
+        cnt = int(sel.sum())
+        low = np.full((cnt, L), ord("A"), dtype=np.uint8)
+        low[:, L - 10:] = ACGT[rng.integers(0, 4, size=(cnt, 10), dtype=np.uint8)]
+        out[sel] = low
+        if paired:
+            outm[sel] = low
+        # N reads: 1-3 positions overwritten
+        sel = np.nonzero(k >= K_LOW)[0]
+        for _ in range(3):
+            take = sel[rng.random(sel.size) < (2.0 / 3.0)] if _ else sel
+            out[take, rng.integers(0, L, size=take.size)] = ord("N")
+        r1[lo:hi] = out
+        if paired:
+            r2[lo:hi] = outm
+    # exact duplicates of an earlier non-duplicate read
+    dup = np.nonzero((kind >= K_OFF) & (kind < K_DUP))[0]
+    nondup = np.nonzero(~((kind >= K_OFF) & (kind < K_DUP)))[0]
+    before = np.searchsorted(nondup, dup)
+    ok = before > 0
+    src = nondup[(rng.random(dup.size) * np.maximum(before, 1)).astype(np.int64)]
+    r1[dup[ok]] = r1[src[ok]]
+    if paired:
+        r2[dup[ok]] = r2[src[ok]]
+    return (r1, r2) if paired else r1
+
+
+def fixed_offsets(n, L):
+    return np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+
+
+def write_fastq(path, reads, prefix="r"):
+    qual = b"I" * reads.shape[1]
+    with open(path, "wb") as f:
+        for i in range(reads.shape[0]):
+            f.write(b"@" + prefix.encode() + str(i).encode() + b"\n" + reads[i].tobytes() + b"\n+\n" + qual + b"\n")
