@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the hot path (score::call: pack -> align -> intern -> dedup -> count -> rows) on MI355X.
+
+Workload at N=1: BASELINE.json configs[2] -- 10 M synthetic 150 bp single-end reads against a 1 k-feature
+(2 k index rows) allele-family library with the basic.json alignment settings; reads are resident in HBM when
+the timed region starts.  A "step" is one complete score::call over the batch, ending with the sorted
+(callset -> count) rows on the host.  At N>1 every rank holds its own 10 M reads (weak scaling) and a step is
+partition -> all-to-all exchange by read key -> score::call per rank -> all-reduce of the count vector (RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel
+(k_align, HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box's host cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    nim = importlib.import_module("nimble-aligner_amd")
+    synth = importlib.import_module("nimble-aligner_amd.synth")
+    nd = importlib.import_module("nimble-aligner_amd.distributed")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    L = 150
+    n = args.reads
+    names, seqs = synth.make_library(args.features)
+    lib_obj = synth.library_json(names, seqs)
+    lib = nim.Library(text=json.dumps(lib_obj), strand_filter="unstranded").build_index(local_rank)
+    ctx = lib.device_context()
+    reads = synth.make_reads_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * rank, device=str(device))
+    torch.cuda.synchronize()
+
+    def compute(a, b=None):
+        torch.cuda.current_stream().synchronize()  # reads produced on torch's stream; the call runs on its own
+        return lib.score_call(a, None, n=a.shape[0], fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+
+    def step():
+        if world > 1:
+            return nd.sharded_call(compute, reads, None, device)
+        return compute(reads)
+
+    # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count
+    ctx.set_counters(True)
+    rows = step()
+    ctx.n = n
+    counters = ctx.counters() if world == 1 else None
+    ctx.set_counters(False)
+
+    for _ in range(args.warmup):
+        rows = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stage = {k: 0.0 for k in ("pack", "align", "intern", "dedup", "count", "total")}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+        for k, v in ctx.timing().items():
+            stage[k] += v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps = max(args.steps, 1)
+    stage = {k: v / steps for k, v in stage.items()}
+    total_reads = n * world * steps
+    value = total_reads / elapsed
+
+    out = {
+        "metric": "reads/sec aligned (whole job), counts bit-exact vs the CPU path",
+        "value": value,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: %d x %dbp single-end reads per GPU vs %d-feature library "
+                        "(%d index rows), basic.json settings (score_percent 0.33, score_threshold 50, "
+                        "num_mismatches 0), unstranded" % (n, L, args.features, 2 * args.features),
+            "reads_per_gpu": n, "read_len": L, "features": args.features,
+            "parallelism": "1 process/GPU; reads hash-partitioned by key (all-to-all) + count all-reduce (RCCL)"
+                           if world > 1 else "single GPU",
+            "rows": len(rows),
+        },
+        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+        "device_reads_per_s": n / (stage["total"] / 1000.0) if stage["total"] > 0 else None,
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (k_align): algorithmic bytes of one launch / its duration
+        P, U, E = counters["probes"], counters["nodes"], counters["class_entries"]
+        hit = counters["seeded"]
+        key_bytes = 8 * ((L + 31) // 32)
+        align_bytes = n * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n
+        pipe_bytes = n * L + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n  # SURVEY 8(d) formula
+        align_s = stage["align"] / 1000.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("reads") == n and tj.get("features") == args.features:
+                    traffic = tj.get("k_align_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "k_align",
+            "achieved": align_bytes / align_s / 1e9,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": align_bytes / align_s / 1e9 / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": align_bytes,
+            "kernel_ms": stage["align"],
+            "bytes_per_read": align_bytes / n,
+            "pipeline": {"algorithmic_bytes_per_read": pipe_bytes / n,
+                         "achieved_GBps": pipe_bytes / (stage["total"] / 1000.0) / 1e9,
+                         "frac": pipe_bytes / (stage["total"] / 1000.0) / 1e9 / HBM_PEAK_GBPS},
+            "counters": {"probes": P, "nodes": U, "class_entries": E, "seeded": hit},
+        }
+        # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same reads
+        if args.cpu_sample > 0:
+            from oracle import oracle as ora
+            S = min(args.cpu_sample, n)
+            sample = reads[:S].cpu().numpy()
+            cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+            ref = ora.Reference.from_columns(lib_obj[1]["headers"], cols, "")
+            cfg = ora.config_from_json(lib_obj[0], len(names), "unstranded")
+            oidx = ora.Index.from_reference(ref)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            offs = synth.fixed_offsets(S, L)
+            t1 = time.perf_counter()
+            ores = ora.call(oidx, ref, cfg, sample.reshape(-1), offs, n_threads=threads)
+            cpu_s = time.perf_counter() - t1
+            S1 = min(S, 200_000)
+            t1 = time.perf_counter()
+            ora.call(oidx, ref, cfg, sample[:S1].reshape(-1), synth.fixed_offsets(S1, L), n_threads=1)
+            cpu1_s = time.perf_counter() - t1
+            # parity on the sample: the GPU table must equal the oracle's table
+            got = lib.score_call(reads[:S].contiguous(), None, n=S, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+            parity = [(f, c) for f, c in got] == [(f, c) for f, c in ores.rows]
+            if not parity:
+                raise SystemExit("bench.py: GPU table differs from the CPU oracle on the sample")
+            out["cpu_baseline"] = {
+                "value": S / cpu_s, "unit": "reads/s", "cores": threads, "kind": "port",
+                "sample": "first %d of the %d reads, oracle/libnimble_oracle.so, %d threads (hash-partitioned by key); "
+                          "index build and read generation excluded" % (S, n, threads),
+                "single_thread_value": S1 / cpu1_s,
+                "parity_on_sample": "bit-exact table (%d rows)" % len(got),
+            }
+            out["speedup_vs_cpu_baseline"] = value / (S / cpu_s)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

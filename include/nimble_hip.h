@@ -94,6 +94,11 @@ int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32
 int nimble_ctx_create(nimble_index *, void *stream, nimble_ctx **out);
 void nimble_ctx_free(nimble_ctx *);
 
+/* Options: NIMBLE_OPT_COUNTERS (default 1) -- collect the work counters of nimble_call_counters inside the
+ * align kernel; switch off for timed runs. */
+enum { NIMBLE_OPT_COUNTERS = 1 };
+int nimble_ctx_set_option(nimble_ctx *, int option, int64_t value);
+
 /* Memory space of the read buffers handed to nimble_call */
 enum { NIMBLE_MEM_HOST = 0, NIMBLE_MEM_DEVICE = 1 };
 

@@ -1,0 +1,96 @@
+/* nimble_host.h -- C ABI over the C++ host mirror (nimble-aligner_amd/host), for bindings and tests.
+ *
+ * The functions follow the reference's own module surface:
+ *   nimble_library_*      reference_library::get_reference_library (src/reference_library.rs:20-174)
+ *                         + utils::get_reference_sequence_data (src/utils.rs:7-24)
+ *                         + build_index::<Kmer30> (src/bin/main.rs:121-128)
+ *   nimble_score_call     score::call (src/score.rs:14-46) over in-memory reads
+ *   nimble_fastq_process  process::fastq::process (src/process/fastq.rs:7-30)
+ *   nimble_write_to_tsv   utils::write_to_tsv (src/utils.rs:27-51)
+ * Rust panics surface as a non-zero return with the reference's message in nimble_host_last_error().
+ */
+#ifndef NIMBLE_HOST_H
+#define NIMBLE_HOST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AlignFilterConfig (src/align.rs:79-95) */
+typedef struct nimble_host_config {
+  uint64_t reference_genome_size;
+  double score_percent;
+  uint64_t score_threshold;
+  uint64_t num_mismatches;
+  int32_t discard_nonzero_mismatch;
+  int32_t discard_multiple_matches;
+  int32_t score_filter;
+  int32_t intersect_level; /* 0 NoIntersect, 1 IntersectWithFallback, 2 ForceIntersect */
+  int32_t require_valid_pair;
+  int32_t strand_filter; /* 0 unstranded, 1 fiveprime, 2 threeprime, 3 none (src/align.rs:97-103) */
+  uint64_t discard_multi_hits;
+  uint64_t max_hits_to_report;
+  double trim_strictness;
+  uint64_t trim_target_length;
+} nimble_host_config;
+
+typedef struct nimble_library nimble_library; /* (AlignFilterConfig, Reference [, PseudoAligner]) */
+typedef struct nimble_rows nimble_rows;       /* Vec<(Vec<String>, i32)> */
+
+const char *nimble_host_last_error(void);
+
+/* get_reference_library(path, strand_filter): host only, no device needed */
+int nimble_library_load(const char *json_path, int strand_filter, nimble_library **out);
+int nimble_library_parse(const char *json_text, int strand_filter, nimble_library **out);
+void nimble_library_free(nimble_library *);
+int nimble_library_get_config(const nimble_library *, nimble_host_config *out);
+int nimble_library_set_config(nimble_library *, const nimble_host_config *in); /* tests mutate the config */
+int nimble_library_n_rows(const nimble_library *);
+int nimble_library_n_cols(const nimble_library *);
+int nimble_library_group_on(const nimble_library *);
+void nimble_library_set_group_on(nimble_library *, int col);
+int nimble_library_sequence_name_idx(const nimble_library *);
+int nimble_library_sequence_idx(const nimble_library *);
+const char *nimble_library_header(const nimble_library *, int col);
+const char *nimble_library_cell(const nimble_library *, int col, int row);
+int nimble_library_push_column(nimble_library *, const char *header, const char *const *values, int n);
+/* get_reference_sequence_data + build_index on `device`; needs a GPU */
+int nimble_library_build_index(nimble_library *, int device);
+/* the device handles behind the library's PseudoAligner (NULL before build_index); borrowed */
+void *nimble_library_index(nimble_library *);
+void *nimble_library_ctx(nimble_library *);
+
+/* score::call.  r2 == NULL for single-end; *_off == NULL means fixed_len; mem as in nimble_hip.h */
+int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                      const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                      nimble_rows **out);
+/* get_error_checked_fastq_readers + score::call */
+int nimble_score_call_fastq(nimble_library *, const char *r1_path, const char *r2_path, nimble_rows **out);
+void nimble_rows_free(nimble_rows *);
+uint64_t nimble_rows_count(const nimble_rows *);
+/* features joined by '\t' (the TSV cell layout) and the count */
+const char *nimble_rows_get(const nimble_rows *, uint64_t i, int32_t *count);
+
+/* fastq::process: libraries must have their index built */
+int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, nimble_library *const *libs,
+                         const char *const *outputs);
+int nimble_write_to_tsv(const nimble_rows *, const char *output_path);
+
+/* host-only pieces, exposed for CPU tests of the host logic */
+/* filter_and_coerce_sequence_call_orientations on explicit classes; callset joined by '\t' into out;
+ * returns the triage FilterReason (16 = None) or -1 on panic */
+int nimble_host_coerce(const nimble_library *, int has_r1, const uint32_t *c1, int n1, int has_r2, const uint32_t *c2,
+                       int n2, char *out, int cap);
+int nimble_host_natural_lexical_cmp(const char *a, const char *b);
+double nimble_host_shannon_entropy(const char *dna);
+int nimble_host_revcomp(const char *seq, char *out); /* out holds strlen(seq)+1 bytes */
+uint64_t nimble_host_maxinfo(const char *quality, int qlen, uint64_t target_length, double strictness);
+/* read_fastq: n reads, total bases, max length; -1 on the reference's panic */
+int nimble_host_read_fastq(const char *path, uint64_t *n, uint64_t *bases, uint32_t *max_len);
+const char *nimble_host_filter_reason_text(int reason); /* Display for FilterReason */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -60,7 +60,7 @@ HIP_SYMBOLS = [
     "nimble_abi_version", "nimble_last_error", "nimble_device_count", "nimble_index_build", "nimble_index_free",
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
-    "nimble_call_timing", "nimble_flat_index_stats",
+    "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option",
 ]
 
 
@@ -86,6 +86,7 @@ def hip_lib():
         L.nimble_ctx_free.argtypes = [vp]
         L.nimble_ctx_free.restype = None
         L.nimble_ctx_synchronize.argtypes = [vp]
+        L.nimble_ctx_set_option.argtypes = [vp, i32, C.c_int64]
         L.nimble_call.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32]
         L.nimble_histogram.argtypes = [vp, vp, vp, vp, u64, C.POINTER(u64)]
         L.nimble_histogram_dense_se.argtypes = [vp, vp, u32]
@@ -179,18 +180,22 @@ class Index:
 class Context:
     """One `score::call` in flight (src/score.rs:14-46): workspace + stream over a shared Index."""
 
-    def __init__(self, index, stream=None):
+    def __init__(self, index=None, stream=None, borrowed=None):
         self.index = index
+        self.n = 0
+        self._keep = None
+        self._owned = borrowed is None
+        if borrowed is not None:  # a context owned by a Library (nimble_library_ctx)
+            self.h = C.c_void_p(borrowed)
+            return
         h = C.c_void_p()
         _check(hip_lib().nimble_ctx_create(index.h, stream, C.byref(h)))
         self.h = h
-        self.n = 0
-        self._keep = None
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self._owned:
             hip_lib().nimble_ctx_free(self.h)
-            self.h = None
+        self.h = None
 
     __del__ = close
 
@@ -221,6 +226,9 @@ class Context:
 
     def synchronize(self):
         _check(hip_lib().nimble_ctx_synchronize(self.h))
+
+    def set_counters(self, on):
+        _check(hip_lib().nimble_ctx_set_option(self.h, 1, int(bool(on))))
 
     def histogram(self):
         """[(class_r1, class_r2, count)] sorted by class ids; CLASS_NONE marks an absent mate call."""
@@ -259,3 +267,268 @@ class Context:
         t = (C.c_float * 6)()
         _check(hip_lib().nimble_call_timing(self.h, t))
         return dict(pack=t[0], align=t[1], intern=t[2], dedup=t[3], count=t[4], total=t[5])
+
+
+# ------------------------------------------------------------------------------------------------
+# Host mirror (lib/libnimble_host.so): reference_library / score::call / FASTQ pipeline in C++
+# ------------------------------------------------------------------------------------------------
+CHEM = {"unstranded": 0, "fiveprime": 1, "threeprime": 2, "none": 3}
+
+HOST_SYMBOLS = [
+    "nimble_host_last_error", "nimble_library_load", "nimble_library_parse", "nimble_library_free",
+    "nimble_library_get_config", "nimble_library_set_config", "nimble_library_n_rows", "nimble_library_n_cols",
+    "nimble_library_group_on", "nimble_library_set_group_on", "nimble_library_sequence_name_idx",
+    "nimble_library_sequence_idx", "nimble_library_header", "nimble_library_cell", "nimble_library_push_column",
+    "nimble_library_build_index", "nimble_library_index", "nimble_library_ctx", "nimble_score_call",
+    "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
+    "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
+    "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
+]
+
+
+class HostConfig(C.Structure):
+    """nimble_host_config == AlignFilterConfig (src/align.rs:79-95)."""
+    _fields_ = [
+        ("reference_genome_size", C.c_uint64), ("score_percent", C.c_double), ("score_threshold", C.c_uint64),
+        ("num_mismatches", C.c_uint64), ("discard_nonzero_mismatch", C.c_int32),
+        ("discard_multiple_matches", C.c_int32), ("score_filter", C.c_int32), ("intersect_level", C.c_int32),
+        ("require_valid_pair", C.c_int32), ("strand_filter", C.c_int32), ("discard_multi_hits", C.c_uint64),
+        ("max_hits_to_report", C.c_uint64), ("trim_strictness", C.c_double), ("trim_target_length", C.c_uint64),
+    ]
+
+
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError("nimble-aligner_amd: %s is missing; run __graft_entry__.build()" % HOST_LIB_PATH)
+        hip_lib()  # dependency (also resolved through the rpath)
+        L = C.CDLL(HOST_LIB_PATH)
+        vp, i32, u32, u64, cp = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_char_p
+        pp = C.POINTER(C.c_char_p)
+        L.nimble_host_last_error.restype = cp
+        L.nimble_library_load.argtypes = [cp, i32, C.POINTER(vp)]
+        L.nimble_library_parse.argtypes = [cp, i32, C.POINTER(vp)]
+        L.nimble_library_free.argtypes = [vp]
+        L.nimble_library_free.restype = None
+        L.nimble_library_get_config.argtypes = [vp, C.POINTER(HostConfig)]
+        L.nimble_library_set_config.argtypes = [vp, C.POINTER(HostConfig)]
+        for f in ("n_rows", "n_cols", "group_on", "sequence_name_idx", "sequence_idx"):
+            getattr(L, "nimble_library_" + f).argtypes = [vp]
+        L.nimble_library_set_group_on.argtypes = [vp, i32]
+        L.nimble_library_set_group_on.restype = None
+        L.nimble_library_header.argtypes = [vp, i32]
+        L.nimble_library_header.restype = cp
+        L.nimble_library_cell.argtypes = [vp, i32, i32]
+        L.nimble_library_cell.restype = cp
+        L.nimble_library_push_column.argtypes = [vp, cp, pp, i32]
+        L.nimble_library_build_index.argtypes = [vp, i32]
+        L.nimble_library_index.argtypes = [vp]
+        L.nimble_library_index.restype = vp
+        L.nimble_library_ctx.argtypes = [vp]
+        L.nimble_library_ctx.restype = vp
+        L.nimble_score_call.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(vp)]
+        L.nimble_score_call_fastq.argtypes = [vp, cp, cp, C.POINTER(vp)]
+        L.nimble_rows_free.argtypes = [vp]
+        L.nimble_rows_free.restype = None
+        L.nimble_rows_count.argtypes = [vp]
+        L.nimble_rows_count.restype = u64
+        L.nimble_rows_get.argtypes = [vp, u64, C.POINTER(C.c_int32)]
+        L.nimble_rows_get.restype = cp
+        L.nimble_fastq_process.argtypes = [i32, pp, i32, C.POINTER(vp), pp]
+        L.nimble_write_to_tsv.argtypes = [vp, cp]
+        L.nimble_host_coerce.argtypes = [vp, i32, vp, i32, i32, vp, i32, cp, i32]
+        L.nimble_host_natural_lexical_cmp.argtypes = [cp, cp]
+        L.nimble_host_shannon_entropy.argtypes = [cp]
+        L.nimble_host_shannon_entropy.restype = C.c_double
+        L.nimble_host_revcomp.argtypes = [cp, cp]
+        L.nimble_host_maxinfo.argtypes = [cp, i32, u64, C.c_double]
+        L.nimble_host_maxinfo.restype = u64
+        L.nimble_host_read_fastq.argtypes = [cp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+        L.nimble_host_filter_reason_text.argtypes = [i32]
+        L.nimble_host_filter_reason_text.restype = cp
+        _host = L
+    return _host
+
+
+class Panic(RuntimeError):
+    """A Rust panic of the reference, surfaced with its message."""
+
+
+def _hcheck(rc):
+    if rc != 0:
+        raise Panic(host_lib().nimble_host_last_error().decode("utf-8", "replace"))
+
+
+def _cstrs(seq):
+    arr = (C.c_char_p * len(seq))()
+    arr[:] = [s.encode("utf-8") if isinstance(s, str) else s for s in seq]
+    return arr
+
+
+def _rows(handle):
+    L = host_lib()
+    try:
+        out = []
+        for i in range(L.nimble_rows_count(handle)):
+            cnt = C.c_int32()
+            s = L.nimble_rows_get(handle, i, C.byref(cnt)).decode()
+            out.append((s.split("\t"), cnt.value))
+        return out
+    finally:
+        L.nimble_rows_free(handle)
+
+
+class Library:
+    """(AlignFilterConfig, Reference) of reference_library::get_reference_library, plus the device index."""
+
+    def __init__(self, path=None, strand_filter="unstranded", text=None):
+        sf = CHEM[strand_filter] if isinstance(strand_filter, str) else int(strand_filter)
+        h = C.c_void_p()
+        if text is not None:
+            _hcheck(host_lib().nimble_library_parse(text.encode(), sf, C.byref(h)))
+        else:
+            _hcheck(host_lib().nimble_library_load(os.fsencode(path), sf, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            host_lib().nimble_library_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def config(self):
+        c = HostConfig()
+        host_lib().nimble_library_get_config(self.h, C.byref(c))
+        return c
+
+    @config.setter
+    def config(self, c):
+        _hcheck(host_lib().nimble_library_set_config(self.h, C.byref(c)))
+
+    def update_config(self, **kw):
+        c = self.config
+        for k, v in kw.items():
+            setattr(c, k, v)
+        self.config = c
+
+    n_rows = property(lambda self: host_lib().nimble_library_n_rows(self.h))
+    n_cols = property(lambda self: host_lib().nimble_library_n_cols(self.h))
+    sequence_name_idx = property(lambda self: host_lib().nimble_library_sequence_name_idx(self.h))
+    sequence_idx = property(lambda self: host_lib().nimble_library_sequence_idx(self.h))
+
+    @property
+    def group_on(self):
+        return host_lib().nimble_library_group_on(self.h)
+
+    @group_on.setter
+    def group_on(self, col):
+        host_lib().nimble_library_set_group_on(self.h, col)
+
+    @property
+    def headers(self):
+        return [host_lib().nimble_library_header(self.h, c).decode() for c in range(self.n_cols)]
+
+    def column(self, c):
+        return [host_lib().nimble_library_cell(self.h, c, r).decode() for r in range(self.n_rows)]
+
+    def push_column(self, header, values):
+        return host_lib().nimble_library_push_column(self.h, header.encode(), _cstrs(values), len(values))
+
+    def build_index(self, device=0):
+        _hcheck(host_lib().nimble_library_build_index(self.h, device))
+        return self
+
+    def score_call(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST):
+        """score::call (src/score.rs:14-46) -> [(features, count)] sorted by callset."""
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        if max_len == 0:
+            if r1_off is not None and isinstance(r1_off, np.ndarray) and n:
+                max_len = int(np.diff(r1_off.astype(np.int64)).max())
+                if r2_off is not None:
+                    max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()))
+            else:
+                max_len = fixed_len
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+                                             max(max_len, 1), mem, C.byref(h)))
+        return _rows(h)
+
+    def score_call_reads(self, reads, mates=None):
+        b1, o1 = pack_reads(reads)
+        if mates is not None:
+            b2, o2 = pack_reads(mates)
+            return self.score_call(b1, o1, b2, o2)
+        return self.score_call(b1, o1)
+
+    def device_context(self):
+        """The device context behind this library's PseudoAligner (stage timings, counters, records)."""
+        p = host_lib().nimble_library_ctx(self.h)
+        if not p:
+            raise Panic("the library has no index")
+        return Context(borrowed=p)
+
+    def align_params(self):
+        c = self.config
+        return AlignParams.make(c.score_percent, c.score_threshold, c.num_mismatches, c.discard_nonzero_mismatch,
+                                c.discard_multiple_matches, c.require_valid_pair)
+
+    def score_call_fastq(self, r1_path, r2_path=None):
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_call_fastq(self.h, os.fsencode(r1_path),
+                                                   os.fsencode(r2_path) if r2_path else None, C.byref(h)))
+        return _rows(h)
+
+    def coerce(self, c1, c2):
+        """Host coercion of one (class R1, class R2) pair -> (callset, triage reason code)."""
+        a1 = np.ascontiguousarray(np.asarray(list(c1 or []), dtype=np.uint32))
+        a2 = np.ascontiguousarray(np.asarray(list(c2 or []), dtype=np.uint32))
+        out = C.create_string_buffer(1 << 18)
+        r = host_lib().nimble_host_coerce(self.h, int(c1 is not None), a1.ctypes.data, a1.size, int(c2 is not None),
+                                          a2.ctypes.data, a2.size, out, len(out))
+        if r < 0:
+            raise Panic(host_lib().nimble_host_last_error().decode("utf-8", "replace"))
+        s = out.value.decode()
+        return (s.split("\t") if s else []), r
+
+
+def fastq_process(input_files, libraries, output_paths):
+    """process::fastq::process (src/process/fastq.rs:7-30)."""
+    arr = (C.c_void_p * len(libraries))(*[l.h for l in libraries])
+    _hcheck(host_lib().nimble_fastq_process(len(input_files), _cstrs(input_files), len(libraries), arr,
+                                            _cstrs(output_paths)))
+
+
+def natural_lexical_cmp(a, b):
+    return host_lib().nimble_host_natural_lexical_cmp(a.encode(), b.encode())
+
+
+def shannon_entropy(s):
+    return host_lib().nimble_host_shannon_entropy(s.encode())
+
+
+def revcomp(s):
+    out = C.create_string_buffer(len(s.encode()) + 1)
+    _hcheck(host_lib().nimble_host_revcomp(s.encode(), out))
+    return out.value.decode()
+
+
+def maxinfo(quality, target_length, strictness):
+    q = quality.encode("latin-1") if isinstance(quality, str) else quality
+    return host_lib().nimble_host_maxinfo(q, len(q), target_length, strictness)
+
+
+def read_fastq_stats(path):
+    n, b, m = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    _hcheck(host_lib().nimble_host_read_fastq(os.fsencode(path), C.byref(n), C.byref(b), C.byref(m)))
+    return n.value, b.value, m.value
+
+
+def filter_reason_text(code):
+    return host_lib().nimble_host_filter_reason_text(code).decode()

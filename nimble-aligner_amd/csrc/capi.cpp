@@ -365,6 +365,15 @@ void nimble_ctx_free(nimble_ctx *c) {
   delete c;
 }
 
+int nimble_ctx_set_option(nimble_ctx *c, int option, int64_t value) {
+  if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
+  if (option == NIMBLE_OPT_COUNTERS) {
+    c->want_counters = value != 0;
+    return NIMBLE_OK;
+  }
+  return fail(NIMBLE_E_INVALID, "nimble_ctx_set_option: unknown option");
+}
+
 int nimble_ctx_synchronize(nimble_ctx *c) {
   if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
   HIPCHK(hipSetDevice(c->ix->device));

@@ -1,0 +1,429 @@
+// align.cpp -- host side of align::get_calls / score::call over the device C ABI.
+//
+// The per-read work (pseudoalign, filters, dedup, counting) runs on the GPU behind
+// include/nimble_hip.h.  What stays here is what the reference does once per *unique read* with
+// strings (filter_and_coerce_sequence_call_orientations, src/align.rs:178-252): it depends only on the
+// (class R1, class R2) pair, so it is evaluated once per distinct pair of the device histogram.
+//
+// The coercion is written over interned strings: every string comparison the reference makes on this
+// path is an equality test or the natural_lexical sort, so names, parsed feature names and group values
+// are interned once per library (equal strings <-> equal ids) and ranked once with natural_lexical_cmp.
+// All of the reference's string quirks are evaluated on the real strings when the tables are built:
+// `ends_with("rev")` / trim_end_matches parsing (align.rs:276-285), strip_suffix("§rev")
+// (align.rs:149,164), first-match `unmap` (align.rs:851-864), the discarded `unique()` (align.rs:794).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_set>
+
+#include "../../include/nimble_hip.h"
+#include "nimble_host.hpp"
+
+namespace nimble {
+namespace align {
+
+namespace {
+
+bool ends_with(const std::string &s, const std::string &suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+std::string trim_end_matches(std::string s, const std::string &pat) {
+  while (!pat.empty() && ends_with(s, pat)) s.resize(s.size() - pat.size());
+  return s;
+}
+
+void check_rc(int rc, const char *what) {
+  if (rc != 0) throw Panic(std::string(what) + ": " + nimble_last_error());
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct Coercer::Impl {
+  AlignFilterConfig cfg;
+  bool no_rollup = false;  // headers[group_on] == "nt_sequence" (align.rs:810)
+  size_t n_rows = 0;
+  // string pool
+  std::vector<std::string> strs;
+  std::unordered_map<std::string, uint32_t> ids;
+  std::vector<uint32_t> rank;  // natural_lexical rank of each pooled string
+  // per row
+  std::vector<uint32_t> row_name;   // sid of the row's sequence_name
+  std::vector<uint32_t> row_group;  // sid of the roll-up value (group value, or name when it is empty)
+  // per pooled string that is a row name
+  std::vector<uint32_t> strip_sid;   // sid of strip_suffix("§rev") (itself when there is no suffix)
+  std::vector<uint8_t> has_suffix;
+  std::vector<uint32_t> parse_sid;   // parse_calls: feature sid
+  std::vector<uint8_t> parse_rev;    // parse_calls: rev flag
+  std::vector<int64_t> first_row;    // unmap: first row whose name is this string, -1 = panic
+
+  uint32_t intern(const std::string &s) {
+    auto it = ids.find(s);
+    if (it != ids.end()) return it->second;
+    uint32_t id = (uint32_t)strs.size();
+    strs.push_back(s);
+    ids.emplace(s, id);
+    return id;
+  }
+
+  typedef std::pair<uint32_t, bool> Call;  // (feature sid, rev)
+
+  void sort_by_rank(std::vector<uint32_t> &v) const {
+    std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+  }
+
+  // process_equivalence_class_to_feature_list(cls, .., ignore_group_rollup = true): names, sorted
+  std::vector<uint32_t> names_of(const std::vector<uint32_t> &cls) const {
+    std::vector<uint32_t> out;
+    out.reserve(cls.size());
+    for (uint32_t r : cls) {
+      if (r >= n_rows) throw Panic("index out of bounds: equivalence class row beyond the reference");
+      out.push_back(row_name[r]);
+    }
+    sort_by_rank(out);
+    return out;
+  }
+
+  // align.rs:144-171
+  std::vector<uint32_t> filter_read_calls_with_orientation(const std::vector<uint32_t> &cls) const {
+    std::unordered_set<uint32_t> seen, to_remove;
+    for (uint32_t f : cls) {
+      uint32_t base = strip_sid[f];
+      if (seen.count(base)) to_remove.insert(base);
+      else seen.insert(base);
+    }
+    std::vector<uint32_t> out;
+    for (uint32_t f : cls) {
+      uint32_t key = has_suffix[f] ? strip_sid[f] : f;
+      if (!to_remove.count(key)) out.push_back(f);
+    }
+    return out;
+  }
+
+  std::vector<Call> parse_calls(const std::vector<uint32_t> &calls) const {
+    std::vector<Call> out;
+    out.reserve(calls.size());
+    for (uint32_t f : calls) out.emplace_back(parse_sid[f], parse_rev[f] != 0);
+    return out;
+  }
+
+  // align.rs:287-309
+  static void filter_unstranded(const std::vector<Call> &seq, const std::vector<Call> &mate, std::vector<Call> &so,
+                                std::vector<Call> &mo) {
+    auto has = [](const std::vector<Call> &v, const Call &c) { return std::find(v.begin(), v.end(), c) != v.end(); };
+    for (const auto &c : seq)
+      if (!has(mate, c)) so.push_back(c);
+    for (const auto &c : mate)
+      if (!has(seq, c)) mo.push_back(c);
+  }
+
+  // align.rs:311-342 (five prime keeps forward calls of the first mate) / :344-375 (three prime keeps reverse)
+  static void filter_prime(const std::vector<Call> &seq, const std::vector<Call> &mate, bool keep_rev,
+                           std::vector<uint32_t> &so, std::vector<uint32_t> &mo) {
+    std::vector<Call> su, mu;
+    filter_unstranded(seq, mate, su, mu);
+    std::vector<Call> kept_seq;
+    std::vector<Call> m = mu;
+    for (const auto &call : su) {
+      if (call.second != keep_rev) {
+        for (size_t p = 0; p < m.size(); ++p)
+          if (m[p].first == call.first) { m.erase(m.begin() + (long)p); break; }
+      } else {
+        kept_seq.push_back(call);
+      }
+    }
+    for (const auto &mc : m) {
+      bool constrained = keep_rev ? mc.second : !mc.second;
+      bool keep = true;
+      if (constrained) {
+        keep = false;
+        for (const auto &s : kept_seq)
+          if (s.first == mc.first) { keep = true; break; }
+      }
+      if (keep) mo.push_back(mc.first);
+    }
+    for (const auto &s : kept_seq) so.push_back(s.first);
+  }
+
+  // process_equivalence_class_to_feature_list(rows, .., ignore_group_rollup = false), align.rs:802-849
+  std::vector<uint32_t> rollup(const std::vector<uint32_t> &rows) const {
+    std::vector<uint32_t> out;
+    if (no_rollup) {
+      for (uint32_t r : rows) out.push_back(row_name[r]);
+    } else {
+      for (uint32_t r : rows) {
+        uint32_t g = row_group[r];
+        if (std::find(out.begin(), out.end(), g) == out.end()) out.push_back(g);
+      }
+    }
+    if (cfg.discard_multi_hits > 0 && out.size() > cfg.discard_multi_hits) return {};
+    sort_by_rank(out);
+    return out;
+  }
+};
+
+Coercer::Coercer(const reference_library::Reference &ref, const AlignFilterConfig &config) : impl_(new Impl()) {
+  Impl &I = *impl_;
+  I.cfg = config;
+  const std::string sep = reference_library::SPECIAL_REVCOMP_FEATURE_NAME_SEPARATOR;
+  const std::string rev_suffix = sep + "rev";
+  const auto &names = ref.columns.at(ref.sequence_name_idx);
+  I.n_rows = names.size();
+  I.no_rollup = ref.headers.at(ref.group_on) == "nt_sequence";
+  const auto &groups = ref.columns.at(ref.group_on);
+  for (size_t r = 0; r < names.size(); ++r) {
+    I.row_name.push_back(I.intern(names[r]));
+    const std::string &g = r < groups.size() ? groups[r] : names[r];
+    I.row_group.push_back(I.intern(g.empty() ? names[r] : g));
+  }
+  // derived strings of every row name (parse / strip); may add new strings to the pool
+  const size_t n_named = I.strs.size();
+  std::vector<std::string> stripped(n_named), parsed(n_named);
+  std::vector<uint8_t> suf(n_named, 0), rev(n_named, 0);
+  for (size_t s = 0; s < n_named; ++s) {
+    const std::string str = I.strs[s];
+    suf[s] = ends_with(str, rev_suffix);
+    stripped[s] = suf[s] ? str.substr(0, str.size() - rev_suffix.size()) : str;
+    if (ends_with(str, "rev")) {
+      parsed[s] = trim_end_matches(trim_end_matches(str, "rev"), sep);
+      rev[s] = 1;
+    } else {
+      parsed[s] = str;
+    }
+  }
+  I.strip_sid.resize(n_named);
+  I.parse_sid.resize(n_named);
+  for (size_t s = 0; s < n_named; ++s) {
+    I.strip_sid[s] = I.intern(stripped[s]);
+    I.parse_sid[s] = I.intern(parsed[s]);
+  }
+  const size_t n_all = I.strs.size();
+  I.strip_sid.resize(n_all);
+  I.parse_sid.resize(n_all);
+  I.has_suffix.assign(n_all, 0);
+  I.parse_rev.assign(n_all, 0);
+  for (size_t s = 0; s < n_named; ++s) { I.has_suffix[s] = suf[s]; I.parse_rev[s] = rev[s]; }
+  for (size_t s = n_named; s < n_all; ++s) { I.strip_sid[s] = (uint32_t)s; I.parse_sid[s] = (uint32_t)s; }
+  // unmap: first row carrying the name
+  I.first_row.assign(n_all, -1);
+  for (size_t r = names.size(); r-- > 0;) I.first_row[I.row_name[r]] = (int64_t)r;
+  // natural-lexical rank of every pooled string
+  std::vector<uint32_t> order(n_all);
+  for (size_t s = 0; s < n_all; ++s) order[s] = (uint32_t)s;
+  std::sort(order.begin(), order.end(),
+            [&](uint32_t a, uint32_t b) { return utils::natural_lexical_cmp(I.strs[a], I.strs[b]) < 0; });
+  I.rank.assign(n_all, 0);
+  for (size_t k = 0; k < n_all; ++k) I.rank[order[k]] = (uint32_t)k;
+}
+
+std::vector<std::string> Coercer::coerce(bool has1, const std::vector<uint32_t> &c1, bool has2,
+                                         const std::vector<uint32_t> &c2, FilterReason &triage) const {
+  const Impl &I = *impl_;
+  triage = FilterReason::None;
+  std::vector<uint32_t> sf, mf;
+  if (has1) sf = I.names_of(c1);
+  if (has2) mf = I.names_of(c2);
+  sf = I.filter_read_calls_with_orientation(sf);
+  mf = I.filter_read_calls_with_orientation(mf);
+  std::vector<Impl::Call> ps = I.parse_calls(sf), pm = I.parse_calls(mf);
+  std::vector<uint32_t> s2, m2;
+  switch (I.cfg.strand_filter) {
+    case LibraryChemistry::None:
+      for (auto &c : ps) s2.push_back(c.first);
+      for (auto &c : pm) m2.push_back(c.first);
+      break;
+    case LibraryChemistry::Unstranded: {
+      std::vector<Impl::Call> a, b;
+      Impl::filter_unstranded(ps, pm, a, b);
+      for (auto &c : a) s2.push_back(c.first);
+      for (auto &c : b) m2.push_back(c.first);
+      break;
+    }
+    case LibraryChemistry::FivePrime: Impl::filter_prime(ps, pm, false, s2, m2); break;
+    case LibraryChemistry::ThreePrime: Impl::filter_prime(ps, pm, true, s2, m2); break;
+  }
+  // align.rs:219-227
+  std::vector<uint32_t> final_callset;
+  auto all_calls = [&]() {  // get_all_calls: append; the reference discards the result of unique()
+    std::vector<uint32_t> v = s2;
+    v.insert(v.end(), m2.begin(), m2.end());
+    return v;
+  };
+  if (I.cfg.intersect_level == IntersectLevel::NoIntersect) {
+    final_callset = all_calls();
+  } else {
+    // array_tool Intersect: unique elements of self (first occurrences) that occur in other
+    std::vector<uint32_t> cls;
+    for (uint32_t x : s2) {
+      if (std::find(cls.begin(), cls.end(), x) != cls.end()) continue;
+      if (std::find(m2.begin(), m2.end(), x) != m2.end()) cls.push_back(x);
+    }
+    if (!cls.empty()) final_callset = cls;
+    else if (I.cfg.intersect_level == IntersectLevel::IntersectWithFallback) final_callset = all_calls();
+    else triage = FilterReason::ForceIntersectFailure;
+  }
+  std::vector<uint32_t> rows;
+  for (uint32_t sid : final_callset) {
+    int64_t r = I.first_row[sid];
+    if (r < 0) throw Panic("Feature not found in reference columns");
+    rows.push_back((uint32_t)r);
+  }
+  std::vector<uint32_t> feature_callset = I.rollup(rows);
+  if (feature_callset.size() > I.cfg.max_hits_to_report) { triage = FilterReason::MaxHitsExceeded; return {}; }
+  if (feature_callset.empty()) { triage = FilterReason::TriageEmptyEquivalenceClass; return {}; }
+  std::vector<std::string> out;
+  for (uint32_t sid : feature_callset) out.push_back(I.strs[sid]);
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+std::unique_ptr<PseudoAligner> PseudoAligner::build_index(const std::vector<std::string> &sequences,
+                                                          const std::vector<std::string> &names, int device) {
+  (void)names;  // names are only carried through by the reference's index; they stay on the host
+  std::vector<uint8_t> buf;
+  std::vector<uint64_t> off(1, 0);
+  for (const auto &s : sequences) {
+    buf.insert(buf.end(), s.begin(), s.end());
+    off.push_back(buf.size());
+  }
+  std::unique_ptr<PseudoAligner> pa(new PseudoAligner());
+  check_rc(nimble_index_build(buf.data(), off.data(), (uint32_t)sequences.size(), device, &pa->index_),
+           "Error -- could not create pseudoaligner index of the reference library");
+  check_rc(nimble_ctx_create(pa->index_, nullptr, &pa->ctx_), "nimble_ctx_create");
+  return pa;
+}
+
+PseudoAligner::~PseudoAligner() {
+  if (ctx_) nimble_ctx_free(ctx_);
+  if (index_) nimble_index_free(index_);
+}
+
+const std::vector<uint32_t> &PseudoAligner::eq_class(uint32_t id) {
+  auto it = class_cache_.find(id);
+  if (it != class_cache_.end()) return it->second;
+  uint32_t len = 0;
+  check_rc(nimble_class_get(index_, id, nullptr, 0, &len), "nimble_class_get");
+  std::vector<uint32_t> v(len);
+  if (len) check_rc(nimble_class_get(index_, id, v.data(), len, &len), "nimble_class_get");
+  return class_cache_.emplace(id, std::move(v)).first->second;
+}
+
+CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
+                     const reference_library::Reference &reference, const AlignFilterConfig &config,
+                     bool want_per_read) {
+  if (mates && mates->n != seqs.n)
+    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  nimble_align_params p;
+  memset(&p, 0, sizeof p);
+  p.score_percent = config.score_percent;
+  p.score_threshold = config.score_threshold;
+  p.num_mismatches = (uint32_t)config.num_mismatches;
+  p.discard_nonzero_mismatch = config.discard_nonzero_mismatch;
+  p.discard_multiple_matches = config.discard_multiple_matches;
+  p.require_valid_pair = config.require_valid_pair;
+  p.min_read_length = (uint32_t)MIN_READ_LENGTH;
+  uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
+  if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
+  check_rc(nimble_call(index.ctx(), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+                       mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
+                       seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
+           "nimble_call");
+  uint64_t ne = 0;
+  check_rc(nimble_histogram(index.ctx(), nullptr, nullptr, nullptr, 0, &ne), "nimble_histogram");
+  std::vector<uint32_t> c1(ne), c2(ne);
+  std::vector<uint64_t> cnt(ne);
+  if (ne) check_rc(nimble_histogram(index.ctx(), c1.data(), c2.data(), cnt.data(), ne, &ne), "nimble_histogram");
+
+  Coercer coercer(reference, config);
+  std::map<std::vector<std::string>, int64_t> results;  // the `results` HashMap of align.rs:434
+  static const std::vector<uint32_t> empty;
+  for (uint64_t e = 0; e < ne; ++e) {
+    bool has1 = c1[e] != NIMBLE_CLASS_NONE, has2 = c2[e] != NIMBLE_CLASS_NONE;
+    FilterReason triage;
+    std::vector<std::string> callset = coercer.coerce(has1, has1 ? index.eq_class(c1[e]) : empty, has2,
+                                                      has2 ? index.eq_class(c2[e]) : empty, triage);
+    if (!callset.empty()) results[callset] += (int64_t)cnt[e];
+  }
+  CallOutput out;
+  for (auto &kv : results) out.rows.emplace_back(kv.first, (int32_t)kv.second);
+  if (want_per_read) {
+    out.per_read.resize(seqs.n);
+    std::vector<int32_t> r[2], s[2];
+    for (int m = 0; m < 2; ++m) {
+      r[m].resize(seqs.n);
+      s[m].resize(seqs.n);
+      check_rc(nimble_read_records(index.ctx(), m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, seqs.n),
+               "nimble_read_records");
+    }
+    for (uint64_t i = 0; i < seqs.n; ++i) {
+      FilterRecord &fr = out.per_read[i];
+      fr.r1 = (FilterReason)r[0][i];
+      fr.r2 = (FilterReason)r[1][i];
+      // the score slot of filter_reasons holds the score only for kept alignments (align.rs:561-572)
+      fr.score1 = fr.r1 == FilterReason::SuccessfulMatch ? (size_t)s[0][i] : 0;
+      fr.score2 = fr.r2 == FilterReason::SuccessfulMatch ? (size_t)s[1][i] : 0;
+      fr.triage = FilterReason::None;
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BAM-only trimming helper (align.rs:873-942)
+namespace {
+double norm_ratio(const std::vector<double> &a, size_t margin) {
+  double mx = std::fabs(a[0]);
+  for (size_t i = 1; i < a.size(); ++i) mx = std::max(mx, std::fabs(a[i]));
+  return (double)INT64_MAX / (mx * (double)margin);
+}
+int64_t as_i64(double v) {  // Rust `as i64`
+  if (std::isnan(v)) return 0;
+  if (v >= 9223372036854775807.0) return INT64_MAX;
+  if (v <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)v;
+}
+}  // namespace
+
+size_t maxinfo(const std::string &quality, size_t target_length, double strictness) {
+  const size_t LONGEST_READ = 1000, MAXQUAL = 60;
+  std::vector<double> ls(LONGEST_READ), qp(MAXQUAL + 1);
+  for (size_t i = 0; i < LONGEST_READ; ++i) {
+    double pow1 = std::exp((double)target_length - (double)i - 1.0);
+    ls[i] = std::log(1.0 / (1.0 + pow1)) + std::log((double)(i + 1)) * (1.0 - strictness);
+  }
+  for (size_t i = 0; i <= MAXQUAL; ++i)
+    qp[i] = std::log(1.0 - std::pow(10.0, -((0.5 + (double)i) / 10.0))) * strictness;
+  double ratio = std::max(norm_ratio(ls, LONGEST_READ * 2), norm_ratio(qp, LONGEST_READ * 2));
+  std::vector<int64_t> lsi(LONGEST_READ), qpi(MAXQUAL + 1);
+  for (size_t i = 0; i < LONGEST_READ; ++i) lsi[i] = as_i64(ls[i] * ratio);
+  for (size_t i = 0; i <= MAXQUAL; ++i) qpi[i] = as_i64(qp[i] * ratio);
+  uint64_t accum = 0;
+  double max_score = -1.7976931348623157e308;
+  size_t pos = 0;
+  for (size_t i = 0; i < quality.size(); ++i) {
+    size_t q = (unsigned char)quality[i];
+    if (q > MAXQUAL) q = MAXQUAL;
+    accum += (uint64_t)qpi[q];
+    int64_t score = (int64_t)((i < LONGEST_READ ? (uint64_t)lsi[i] : 0ULL) + accum);
+    if ((double)score >= max_score) { max_score = (double)score; pos = i + 1; }
+  }
+  if (pos < 1 || max_score == 0.0) return 0;
+  return pos < quality.size() ? pos : quality.size();
+}
+
+}  // namespace align
+
+namespace score {
+align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch *mate_sequences,
+                       align::PseudoAligner &reference_index, const reference_library::Reference &reference,
+                       const align::AlignFilterConfig &aligner_config, bool want_per_read) {
+  align::CallOutput out = align::get_calls(sequences, mate_sequences, reference_index, reference, aligner_config,
+                                           want_per_read);
+  // utils::sort_score_vector (utils.rs:54-59): Vec<String> ordering, byte-wise per string
+  std::sort(out.rows.begin(), out.rows.end(),
+            [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+  return out;
+}
+}  // namespace score
+
+}  // namespace nimble

@@ -1,0 +1,256 @@
+// host_capi.cpp -- C ABI of the host mirror (include/nimble_host.h).
+#include <cstring>
+
+#include "../../include/nimble_hip.h"
+#include "../../include/nimble_host.h"
+#include "nimble_host.hpp"
+
+using namespace nimble;
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+std::string join_tab(const std::vector<std::string> &v) {
+  std::string s;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (i) s.push_back('\t');
+    s += v[i];
+  }
+  return s;
+}
+}  // namespace
+
+struct nimble_library {
+  align::AlignFilterConfig cfg;
+  reference_library::Reference ref;
+  std::unique_ptr<align::PseudoAligner> index;
+};
+struct nimble_rows {
+  std::vector<align::ScoreRow> rows;
+  std::vector<std::string> joined;
+};
+
+extern "C" {
+
+const char *nimble_host_last_error(void) { return g_err.c_str(); }
+
+int nimble_library_load(const char *path, int strand_filter, nimble_library **out) {
+  *out = nullptr;
+  return guarded([&] {
+    auto pr = reference_library::get_reference_library(path, (align::LibraryChemistry)strand_filter);
+    nimble_library *l = new nimble_library();
+    l->cfg = pr.first;
+    l->ref = std::move(pr.second);
+    *out = l;
+  });
+}
+int nimble_library_parse(const char *text, int strand_filter, nimble_library **out) {
+  *out = nullptr;
+  return guarded([&] {
+    auto pr = reference_library::parse_reference_library(text, (align::LibraryChemistry)strand_filter);
+    nimble_library *l = new nimble_library();
+    l->cfg = pr.first;
+    l->ref = std::move(pr.second);
+    *out = l;
+  });
+}
+void nimble_library_free(nimble_library *l) { delete l; }
+
+int nimble_library_get_config(const nimble_library *l, nimble_host_config *o) {
+  const auto &c = l->cfg;
+  o->reference_genome_size = c.reference_genome_size;
+  o->score_percent = c.score_percent;
+  o->score_threshold = c.score_threshold;
+  o->num_mismatches = c.num_mismatches;
+  o->discard_nonzero_mismatch = c.discard_nonzero_mismatch;
+  o->discard_multiple_matches = c.discard_multiple_matches;
+  o->score_filter = c.score_filter;
+  o->intersect_level = (int)c.intersect_level;
+  o->require_valid_pair = c.require_valid_pair;
+  o->strand_filter = (int)c.strand_filter;
+  o->discard_multi_hits = c.discard_multi_hits;
+  o->max_hits_to_report = c.max_hits_to_report;
+  o->trim_strictness = c.trim_strictness;
+  o->trim_target_length = c.trim_target_length;
+  return 0;
+}
+int nimble_library_set_config(nimble_library *l, const nimble_host_config *i) {
+  align::AlignFilterConfig c = l->cfg;
+  c.reference_genome_size = i->reference_genome_size;
+  c.score_percent = i->score_percent;
+  c.score_threshold = i->score_threshold;
+  c.num_mismatches = i->num_mismatches;
+  c.discard_nonzero_mismatch = i->discard_nonzero_mismatch != 0;
+  c.discard_multiple_matches = i->discard_multiple_matches != 0;
+  c.score_filter = i->score_filter;
+  c.intersect_level = (align::IntersectLevel)i->intersect_level;
+  c.require_valid_pair = i->require_valid_pair != 0;
+  c.strand_filter = (align::LibraryChemistry)i->strand_filter;
+  c.discard_multi_hits = i->discard_multi_hits;
+  c.max_hits_to_report = i->max_hits_to_report;
+  c.trim_strictness = i->trim_strictness;
+  c.trim_target_length = i->trim_target_length;
+  return guarded([&] {
+    reference_library::sanity_check_align_config(c);
+    l->cfg = c;
+  });
+}
+int nimble_library_n_rows(const nimble_library *l) { return l->ref.columns.empty() ? 0 : (int)l->ref.columns[0].size(); }
+int nimble_library_n_cols(const nimble_library *l) { return (int)l->ref.columns.size(); }
+int nimble_library_group_on(const nimble_library *l) { return (int)l->ref.group_on; }
+void nimble_library_set_group_on(nimble_library *l, int col) { l->ref.group_on = (size_t)col; }
+int nimble_library_sequence_name_idx(const nimble_library *l) { return (int)l->ref.sequence_name_idx; }
+int nimble_library_sequence_idx(const nimble_library *l) { return (int)l->ref.sequence_idx; }
+const char *nimble_library_header(const nimble_library *l, int c) { return l->ref.headers.at((size_t)c).c_str(); }
+const char *nimble_library_cell(const nimble_library *l, int c, int r) {
+  return l->ref.columns.at((size_t)c).at((size_t)r).c_str();
+}
+int nimble_library_push_column(nimble_library *l, const char *header, const char *const *values, int n) {
+  l->ref.headers.push_back(header);
+  std::vector<std::string> col;
+  for (int i = 0; i < n; ++i) col.push_back(values[i]);
+  l->ref.columns.push_back(col);
+  return (int)l->ref.columns.size() - 1;
+}
+int nimble_library_build_index(nimble_library *l, int device) {
+  return guarded([&] {
+    auto data = utils::get_reference_sequence_data(l->ref);
+    l->index = align::PseudoAligner::build_index(data.first, data.second, device);
+  });
+}
+void *nimble_library_index(nimble_library *l) { return l->index ? (void *)l->index->index() : nullptr; }
+void *nimble_library_ctx(nimble_library *l) { return l->index ? (void *)l->index->ctx() : nullptr; }
+
+static nimble_rows *make_rows(align::CallOutput &&o) {
+  nimble_rows *r = new nimble_rows();
+  r->rows = std::move(o.rows);
+  for (auto &row : r->rows) r->joined.push_back(join_tab(row.first));
+  return r;
+}
+
+int nimble_score_call(nimble_library *l, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                      const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                      nimble_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call: the library has no index (call nimble_library_build_index)");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    *out = make_rows(score::call(b1, r2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
+  });
+}
+
+int nimble_score_call_fastq(nimble_library *l, const char *p1, const char *p2, nimble_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_fastq: the library has no index");
+    parse::fastq::FastqData d1 = parse::fastq::read_fastq(p1, false), d2;
+    align::ReadBatch b1, b2;
+    b1.bases = d1.bases.data();
+    b1.offsets = d1.offsets.data();
+    b1.n = d1.n();
+    b1.max_len = d1.max_len;
+    if (p2) {
+      d2 = parse::fastq::read_fastq(p2, true);
+      if (d2.n() < d1.n()) throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+      b2.bases = d2.bases.data();
+      b2.offsets = d2.offsets.data();
+      b2.n = d1.n();
+      b2.max_len = d2.max_len;
+    }
+    *out = make_rows(score::call(b1, p2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
+  });
+}
+
+void nimble_rows_free(nimble_rows *r) { delete r; }
+uint64_t nimble_rows_count(const nimble_rows *r) { return r->rows.size(); }
+const char *nimble_rows_get(const nimble_rows *r, uint64_t i, int32_t *count) {
+  *count = r->rows.at(i).second;
+  return r->joined.at(i).c_str();
+}
+
+int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, nimble_library *const *libs,
+                         const char *const *outputs) {
+  return guarded([&] {
+    std::vector<std::string> in, out;
+    for (int i = 0; i < n_inputs; ++i) in.push_back(inputs[i]);
+    std::vector<std::unique_ptr<align::PseudoAligner>> idx;
+    std::vector<reference_library::Reference> refs;
+    std::vector<align::AlignFilterConfig> cfgs;
+    for (int i = 0; i < n_libs; ++i) {
+      if (!libs[i]->index) throw Panic("nimble_fastq_process: a library has no index");
+      idx.push_back(std::move(libs[i]->index));  // process() consumes the indices, as the reference does
+      refs.push_back(libs[i]->ref);
+      cfgs.push_back(libs[i]->cfg);
+      out.push_back(outputs[i]);
+    }
+    try {
+      process::fastq::process(in, idx, refs, cfgs, out);
+    } catch (...) {
+      for (int i = 0; i < n_libs; ++i) libs[i]->index = std::move(idx[(size_t)i]);
+      throw;
+    }
+    for (int i = 0; i < n_libs; ++i) libs[i]->index = std::move(idx[(size_t)i]);
+  });
+}
+
+int nimble_write_to_tsv(const nimble_rows *r, const char *path) {
+  return guarded([&] { utils::write_to_tsv(r->rows, path); });
+}
+
+int nimble_host_coerce(const nimble_library *l, int has1, const uint32_t *c1, int n1, int has2, const uint32_t *c2,
+                       int n2, char *out, int cap) {
+  int triage = -1;
+  int rc = guarded([&] {
+    align::Coercer co(l->ref, l->cfg);
+    align::FilterReason t;
+    std::vector<std::string> cs = co.coerce(has1 != 0, std::vector<uint32_t>(c1, c1 + n1), has2 != 0,
+                                            std::vector<uint32_t>(c2, c2 + n2), t);
+    std::string j = join_tab(cs);
+    if ((int)j.size() + 1 > cap) throw Panic("output buffer too small");
+    memcpy(out, j.c_str(), j.size() + 1);
+    triage = (int)t;
+  });
+  return rc ? -1 : triage;
+}
+int nimble_host_natural_lexical_cmp(const char *a, const char *b) { return utils::natural_lexical_cmp(a, b); }
+double nimble_host_shannon_entropy(const char *dna) { return utils::shannon_entropy(dna); }
+int nimble_host_revcomp(const char *seq, char *out) {
+  return guarded([&] {
+    std::string r = utils::revcomp(seq);
+    memcpy(out, r.c_str(), r.size() + 1);
+  });
+}
+uint64_t nimble_host_maxinfo(const char *q, int qlen, uint64_t target, double strictness) {
+  return align::maxinfo(std::string(q, (size_t)qlen), (size_t)target, strictness);
+}
+int nimble_host_read_fastq(const char *path, uint64_t *n, uint64_t *bases, uint32_t *max_len) {
+  return guarded([&] {
+    parse::fastq::FastqData d = parse::fastq::read_fastq(path, false);
+    *n = d.n();
+    *bases = d.bases.size();
+    *max_len = d.max_len;
+  });
+}
+const char *nimble_host_filter_reason_text(int r) { return align::to_string((align::FilterReason)r); }
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// nimble_host.hpp -- C++ host mirror of the reference's interfaces around the hot path.
+//
+// The reference is a Rust crate; its toolchain is absent from this image, so the host side above the
+// device C ABI (include/nimble_hip.h) is written in C++ with the same module / function names,
+// argument meaning and error behaviour:
+//   nimble::reference_library  <-  src/reference_library.rs
+//   nimble::utils              <-  src/utils.rs
+//   nimble::align              <-  src/align.rs   (types, get_calls, coercion of class pairs)
+//   nimble::score              <-  src/score.rs   (call)
+//   nimble::parse::fastq       <-  src/parse/fastq.rs
+//   nimble::process::fastq     <-  src/process/fastq.rs
+// Rust panics become nimble::Panic exceptions carrying the reference's message text.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+struct nimble_index;
+struct nimble_ctx;
+
+namespace nimble {
+
+struct Panic : std::runtime_error {
+  explicit Panic(const std::string &m) : std::runtime_error(m) {}
+};
+
+namespace align {
+
+// src/align.rs:25-30
+enum class IntersectLevel { NoIntersect = 0, IntersectWithFallback = 1, ForceIntersect = 2 };
+// src/align.rs:97-103
+enum class LibraryChemistry { Unstranded = 0, FivePrime = 1, ThreePrime = 2, None = 3 };
+// src/align.rs:33-51
+enum class FilterReason {
+  ScoreBelowThreshold = 0, DiscardedMultipleMatch, DiscardedNonzeroMismatch, NoMatch, NoMatchAndScoreBelowThreshold,
+  DifferentFilterReasons, NotMatchingPair, ForceIntersectFailure, ShortRead, MaxHitsExceeded, HighEntropy,
+  SuccessfulMatch, StrandWasWrong, TriageEmptyEquivalenceClass, AboveMismatchThreshold,
+  SkippedAlignDueToUnpairedDummy, None
+};
+const char *to_string(FilterReason r);  // Display impl, src/align.rs:53-77
+
+// src/align.rs:79-95
+struct AlignFilterConfig {
+  size_t reference_genome_size = 0;
+  double score_percent = 0.0;
+  size_t score_threshold = 0;
+  size_t num_mismatches = 0;
+  bool discard_nonzero_mismatch = false;
+  bool discard_multiple_matches = false;
+  int32_t score_filter = 0;
+  IntersectLevel intersect_level = IntersectLevel::NoIntersect;
+  bool require_valid_pair = false;
+  size_t discard_multi_hits = 0;
+  size_t max_hits_to_report = 0;
+  LibraryChemistry strand_filter = LibraryChemistry::Unstranded;
+  double trim_strictness = 0.0;
+  size_t trim_target_length = 0;
+};
+
+constexpr size_t MIN_READ_LENGTH = 40;        // src/align.rs:18
+constexpr double MIN_ENTROPY_SCORE = 1.75;    // src/align.rs:19
+
+}  // namespace align
+
+namespace reference_library {
+
+extern const char *const SPECIAL_REVCOMP_FEATURE_NAME_SEPARATOR;  // "§", reference_library.rs:8
+
+// reference_library.rs:10-17
+struct Reference {
+  size_t group_on = 0;
+  std::vector<std::string> headers;
+  std::vector<std::vector<std::string>> columns;
+  size_t sequence_name_idx = 0;
+  size_t sequence_idx = 0;
+};
+
+// reference_library.rs:20-174
+std::pair<align::AlignFilterConfig, Reference> get_reference_library(const std::string &path,
+                                                                     align::LibraryChemistry strand_filter);
+// same, from JSON text already in memory
+std::pair<align::AlignFilterConfig, Reference> parse_reference_library(const std::string &json_text,
+                                                                       align::LibraryChemistry strand_filter);
+// reference_library.rs:209-226
+void sanity_check_align_config(const align::AlignFilterConfig &cfg);
+
+}  // namespace reference_library
+
+namespace utils {
+
+// utils.rs:7-24: (sequences as ASCII, names); the device index applies from_acgt_bytes itself
+std::pair<std::vector<std::string>, std::vector<std::string>> get_reference_sequence_data(
+    const reference_library::Reference &reference);
+// utils.rs:27-51
+void write_to_tsv(const std::vector<std::pair<std::vector<std::string>, int32_t>> &results,
+                  const std::string &output_path);
+// utils.rs:61-94
+std::string revcomp(const std::string &sequence);
+// utils.rs:96-119
+double shannon_entropy(const std::string &dna);
+// lexical_sort::natural_lexical_cmp as used at align.rs:846
+int natural_lexical_cmp(const std::string &a, const std::string &b);
+
+}  // namespace utils
+
+namespace align {
+
+// Replaces `PseudoAligner` (src/align.rs:21): the device-resident index plus a calling context.
+class PseudoAligner {
+ public:
+  // build_index::<Kmer30>(&seqs, &names, &HashMap::new(), threads) -- src/bin/main.rs:121-128
+  static std::unique_ptr<PseudoAligner> build_index(const std::vector<std::string> &sequences,
+                                                    const std::vector<std::string> &names, int device = 0);
+  ~PseudoAligner();
+  nimble_index *index() const { return index_; }
+  nimble_ctx *ctx() const { return ctx_; }
+  const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
+
+ private:
+  PseudoAligner() = default;
+  nimble_index *index_ = nullptr;
+  nimble_ctx *ctx_ = nullptr;
+  std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
+};
+
+// A batch of reads in memory: concatenated ASCII bases + n+1 offsets (what the reference's boxed
+// iterators of Result<DnaString> yield, materialised).  `device` marks buffers already in HBM.
+struct ReadBatch {
+  const uint8_t *bases = nullptr;
+  const uint64_t *offsets = nullptr;  // nullptr => fixed_len
+  uint64_t n = 0;
+  uint32_t fixed_len = 0;
+  uint32_t max_len = 0;
+  bool device = false;
+};
+
+// One row of the result: (callset, (count, metadata, metadata)); metadata is empty on the FASTQ path
+typedef std::pair<std::vector<std::string>, int32_t> ScoreRow;
+
+struct FilterRecord {  // value of the filter_reasons map, src/align.rs:408
+  FilterReason r1, r2;
+  size_t score1, score2;
+  FilterReason triage;
+};
+
+struct CallOutput {
+  std::vector<ScoreRow> rows;  // unsorted from get_calls, sorted from score::call
+  // filled only when requested: read index -> reasons (the reference keys this by read string)
+  std::vector<FilterRecord> per_read;
+};
+
+// align::get_calls (src/align.rs:392-467).  mates == nullptr for single-end.
+CallOutput get_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
+                     const reference_library::Reference &reference, const AlignFilterConfig &config,
+                     bool want_per_read = false);
+
+// The coercion of one (class R1, class R2) pair into a callset: filter_and_coerce_sequence_call_orientations
+// (src/align.rs:178-252).  Pure host code; evaluated once per distinct pair of a call.
+class Coercer {
+ public:
+  Coercer(const reference_library::Reference &reference, const AlignFilterConfig &config);
+  // returns the callset (empty when triaged) and sets `triage`
+  std::vector<std::string> coerce(bool has1, const std::vector<uint32_t> &c1, bool has2,
+                                  const std::vector<uint32_t> &c2, FilterReason &triage) const;
+
+ private:
+  struct Impl;
+  std::shared_ptr<Impl> impl_;
+};
+
+// BAM-only quality trimming (src/align.rs:866-942), kept for parity of the unit-level surface
+size_t maxinfo(const std::string &quality, size_t target_length, double strictness);
+
+}  // namespace align
+
+namespace score {
+// score::call (src/score.rs:14-46): get_calls + rows sorted by callset
+align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch *mate_sequences,
+                       align::PseudoAligner &reference_index, const reference_library::Reference &reference,
+                       const align::AlignFilterConfig &aligner_config, bool want_per_read = false);
+}  // namespace score
+
+namespace parse {
+namespace fastq {
+// An in-memory FASTQ file: what get_error_checked_fastq_readers (src/parse/fastq.rs:8-43) iterates.
+// Reads plain or gzip-compressed files (niffler auto-detection by magic bytes).
+struct FastqData {
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets;  // n+1
+  uint32_t max_len = 0;
+  uint64_t n() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+};
+// Panics with "Error -- could not parse read. Input R1 data malformed." (src/align.rs:517) /
+// "... reverse read. Input R2 data malformed." (src/align.rs:541) on a malformed record.
+FastqData read_fastq(const std::string &path, bool is_mate);
+}  // namespace fastq
+}  // namespace parse
+
+namespace process {
+namespace fastq {
+// src/process/fastq.rs:7-30
+void process(const std::vector<std::string> &input_files,
+             std::vector<std::unique_ptr<align::PseudoAligner>> &reference_indices,
+             const std::vector<reference_library::Reference> &references,
+             const std::vector<align::AlignFilterConfig> &aligner_configs,
+             const std::vector<std::string> &output_paths);
+}  // namespace fastq
+}  // namespace process
+
+}  // namespace nimble

@@ -169,3 +169,60 @@ def write_fastq(path, reads, prefix="r"):
     with open(path, "wb") as f:
         for i in range(reads.shape[0]):
             f.write(b"@" + prefix.encode() + str(i).encode() + b"\n" + reads[i].tobytes() + b"\n+\n" + qual + b"\n")
+
+
+def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 << 20):
+    """Same recipe as make_reads (single-end) with torch ops, generating straight into device memory.
+    Returns a uint8 tensor [n, L] on `device`.  Deterministic for (n, seed) on a given torch build."""
+    import torch
+
+    cat_np, off_np = _codes(seqs)
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed + n))
+    cat = torch.from_numpy(cat_np).to(dev)
+    off = torch.from_numpy(off_np).to(dev)
+    lens = off[1:] - off[:-1]
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    T = len(seqs)
+    out = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    kind = torch.rand(n, generator=g, device=dev)
+    K_ON, K_OFF, K_DUP, K_LOW = 0.75, 0.90, 0.95, 0.98
+    ar = torch.arange(L, device=dev)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        m = hi - lo
+        k = kind[lo:hi]
+        f = torch.randint(0, T, (m,), generator=g, device=dev)
+        flen = lens[f]
+        start = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (flen - L + 1).double()).long()
+        codes = cat[(off[f] + start)[:, None] + ar]
+        strand = torch.rand(m, generator=g, device=dev) < 0.5
+        rc = 3 - codes.flip(1)
+        codes = torch.where(strand[:, None], rc, codes)
+        mask = torch.rand((m, L), generator=g, device=dev) < 0.005
+        bump = torch.randint(1, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)
+        codes = torch.where(mask, (codes + bump) % 4, codes)
+        rnd = torch.randint(0, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)
+        offt = (k >= K_ON) & (k < K_OFF)
+        codes = torch.where(offt[:, None], rnd, codes)
+        low = (k >= K_DUP) & (k < K_LOW)
+        lowc = rnd.clone()
+        lowc[:, : L - 10] = 0
+        codes = torch.where(low[:, None], lowc, codes)
+        asc = acgt[codes.long()]
+        nsel = torch.nonzero(k >= K_LOW).flatten()
+        for rep in range(3):
+            take = nsel if rep == 0 else nsel[torch.rand(nsel.numel(), generator=g, device=dev) < (2.0 / 3.0)]
+            pos = torch.randint(0, L, (take.numel(),), generator=g, device=dev)
+            asc[take, pos] = ord("N")
+        out[lo:hi] = asc
+    isdup = (kind >= K_OFF) & (kind < K_DUP)
+    dup = torch.nonzero(isdup).flatten()
+    nondup = torch.nonzero(~isdup).flatten()
+    before = torch.searchsorted(nondup, dup)
+    ok = before > 0
+    pick = (torch.rand(dup.numel(), generator=g, device=dev, dtype=torch.float64) * before.clamp(min=1).double()).long()
+    src = nondup[pick]
+    out[dup[ok]] = out[src[ok]]
+    return out

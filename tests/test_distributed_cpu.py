@@ -1,0 +1,105 @@
+"""world_size-2 rehearsal of the multi-GPU step on CPU (gloo): key partition, all-to-all exchange and the
+all-reduce of the count vector, with the CPU oracle injected as the per-rank compute.  The merged table must
+equal a single-process call over all reads -- the property that makes record sharding exact.
+"""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as ora
+
+synth = importlib.import_module("nimble-aligner_amd.synth")
+nd = importlib.import_module("nimble-aligner_amd.distributed")
+
+HEADERS = ["reference_genome", "sequence_name", "nt_length", "sequence"]
+
+
+def _oracle_setup(T=24):
+    names, seqs = synth.make_library(T)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(synth.library_json(names, seqs)[0], len(names), "unstranded")
+    return seqs, ref, cfg, ora.Index.from_reference(ref)
+
+
+def _reads(seqs, paired, n=6000):
+    if paired:
+        return synth.make_reads(seqs, n, paired=True, seed=21)
+    return synth.make_reads(seqs, n, seed=20), None
+
+
+def _worker(rank, world, port, paired, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seqs, ref, cfg, idx = _oracle_setup()
+        r1, r2 = _reads(seqs, paired)
+        # each rank starts from its own slice of the input (record sharding)
+        sl = slice(rank * len(r1) // world, (rank + 1) * len(r1) // world)
+        t1 = torch.from_numpy(r1[sl].copy())
+        t2 = torch.from_numpy(r2[sl].copy()) if paired else None
+
+        def compute(a, b):
+            n = a.shape[0]
+            o = synth.fixed_offsets(n, a.shape[1])
+            if b is not None:
+                return ora.call(idx, ref, cfg, a.numpy().reshape(-1), o, b.numpy().reshape(-1), o).rows
+            return ora.call(idx, ref, cfg, a.numpy().reshape(-1), o).rows
+
+        rows = nd.sharded_call(compute, t1, t2, torch.device("cpu"))
+        torch.save(rows, os.path.join(out_dir, "rows%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_two_rank_sharded_call_equals_single_call(tmp_path, paired):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), paired, str(tmp_path)), nprocs=world, join=True)
+    seqs, ref, cfg, idx = _oracle_setup()
+    r1, r2 = _reads(seqs, paired)
+    o = synth.fixed_offsets(len(r1), 150)
+    if paired:
+        exp = ora.call(idx, ref, cfg, r1.reshape(-1), o, r2.reshape(-1), o).rows
+    else:
+        exp = ora.call(idx, ref, cfg, r1.reshape(-1), o).rows
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "rows%d.pt" % rank))
+        assert [(list(f), c) for f, c in got] == [(f, c) for f, c in exp]
+    # naive record sharding (no key partition) is NOT exact: duplicates straddling shards count twice
+    half = len(r1) // 2
+    naive = {}
+    for sl in (slice(0, half), slice(half, None)):
+        oo = synth.fixed_offsets(len(r1[sl]), 150)
+        part = ora.call(idx, ref, cfg, r1[sl].reshape(-1), oo, *( (r2[sl].reshape(-1), oo) if paired else ()))
+        for f, c in part.rows:
+            naive[tuple(f)] = naive.get(tuple(f), 0) + c
+    assert sum(naive.values()) > sum(c for _, c in exp)
+
+
+def test_key_partition_colocates_duplicates():
+    seqs, *_ = _oracle_setup()
+    r1 = torch.from_numpy(synth.make_reads(seqs, 4000, seed=5))
+    dest = nd.key_partition(r1, None, 8)
+    assert dest.min() >= 0 and dest.max() < 8
+    # identical rows -> identical destination
+    _, inverse = torch.unique(r1, dim=0, return_inverse=True)
+    for k in torch.unique(inverse)[:200]:
+        assert torch.unique(dest[inverse == k]).numel() == 1
+    # reasonably balanced
+    assert torch.bincount(dest, minlength=8).min() > 300
