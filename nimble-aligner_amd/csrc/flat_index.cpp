@@ -136,8 +136,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   // 4. unitigs
   const size_t n_nodes = heads.size();
   out.n_nodes = n_nodes;
-  out.node_hdr.assign(n_nodes * 4, 0);
-  out.node_redge.assign(n_nodes * 4, 0);
+  out.node_rec.assign(n_nodes * 16, 0);
   out.node_ledge.assign(n_nodes * 4, 0);
   std::vector<uint32_t> kmer_node(n), kmer_off(n);
   std::vector<uint32_t> tail(n_nodes);
@@ -152,30 +151,41 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     tail[nd] = last;
     uint64_t len = (uint64_t)o + KMER - 1;
     if (bases + len >= (1ULL << 32)) throw std::runtime_error("index build: unitig buffer exceeds 2^32 bases");
-    out.node_hdr[nd * 4 + 0] = (uint32_t)bases;
-    out.node_hdr[nd * 4 + 1] = (uint32_t)len;
-    out.node_hdr[nd * 4 + 2] = colour[heads[nd]];
-    out.node_hdr[nd * 4 + 3] = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
+    out.node_rec[nd * 16 + 0] = (uint32_t)len;
+    out.node_rec[nd * 16 + 1] = colour[heads[nd]];
+    out.node_rec[nd * 16 + 2] = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
+    out.node_rec[nd * 16 + 3] = (uint32_t)bases;
     bases += len;
   }
   out.unitig_bases = bases;
   out.unitig.assign((bases + 31) / 32 + 4, 0);  // +4 words so a 3-word window never reads past the end
   auto put_base = [&](uint64_t pos, uint64_t b) { out.unitig[pos >> 5] |= b << (62 - 2 * (pos & 31)); };
   for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint64_t pos = out.node_hdr[nd * 4 + 0];
+    uint64_t pos = out.node_rec[nd * 16 + 3];
+    uint64_t inl[4] = {0, 0, 0, 0};
+    uint32_t k = 0;
+    auto put = [&](uint64_t b) {
+      put_base(pos++, b);
+      if (k < NODE_INLINE_BASES) inl[k >> 5] |= b << (62 - 2 * (k & 31));
+      ++k;
+    };
     uint64_t first = kmers[heads[nd]];
-    for (uint32_t b = 0; b < KMER; ++b) put_base(pos++, (first >> (2 * (KMER - 1 - b))) & 3);
-    for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put_base(pos++, kmers[c] & 3);
+    for (uint32_t b = 0; b < KMER; ++b) put((first >> (2 * (KMER - 1 - b))) & 3);
+    for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put(kmers[c] & 3);
+    for (int w = 0; w < 4; ++w) {
+      out.node_rec[nd * 16 + 8 + 2 * w] = (uint32_t)inl[w];
+      out.node_rec[nd * 16 + 9 + 2 * w] = (uint32_t)(inl[w] >> 32);
+    }
   }
   // 5. edges
   for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint32_t e = out.node_hdr[nd * 4 + 3];
+    uint32_t e = out.node_rec[nd * 16 + 2];
     uint64_t firstk = kmers[heads[nd]], lastk = kmers[tail[nd]];
     for (uint32_t b = 0; b < 4; ++b) {
       if ((e >> 4) & (1u << b)) {
         size_t j = find(((lastk << 2) | b) & KMER_MASK);
         if (kmer_off[j] != 0) throw std::runtime_error("index build: right edge does not land on a unitig start");
-        out.node_redge[nd * 4 + b] = kmer_node[j];
+        out.node_rec[nd * 16 + 4 + b] = kmer_node[j];
       }
       if (e & (1u << b)) {
         size_t j = find(((uint64_t)b << (2 * (KMER - 1))) | (firstk >> 2));
@@ -186,15 +196,31 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   }
   // 6. dictionary, load factor <= 0.5
   uint64_t slots = 64;
-  while (slots < 2 * (uint64_t)n + 2) slots <<= 1;
+  uint32_t log2_slots = 6;
+  while (slots < 2 * (uint64_t)n + 2) { slots <<= 1; ++log2_slots; }
   out.ht_slots = slots;
+  out.ht_log2 = log2_slots;
   out.ht.assign(slots * 2, 0);
   for (uint64_t s = 0; s < slots; ++s) out.ht[2 * s] = HT_EMPTY;
   for (size_t i = 0; i < n; ++i) {
-    uint64_t h = mix64(kmers[i]) & (slots - 1);
+    uint64_t h = kmer_slot(kmers[i], log2_slots);
     while (out.ht[2 * h] != HT_EMPTY) h = (h + 1) & (slots - 1);
     out.ht[2 * h] = kmers[i];
     out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
+  }
+  out.bm_log2 = log2_slots + 2;
+  out.bitmap.assign((size_t)1 << (out.bm_log2 - 5), 0);
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t b = kmer_slot(kmers[i], out.bm_log2);
+    out.bitmap[b >> 5] |= 1u << (b & 31);
+  }
+  // 7. class descriptors
+  out.cls_desc.assign(out.n_colours * 8, 0);
+  for (size_t c = 0; c < out.n_colours; ++c) {
+    uint32_t o = out.col_off[c], l = out.col_off[c + 1] - o;
+    out.cls_desc[c * 8 + 0] = l;
+    out.cls_desc[c * 8 + 1] = o;
+    for (uint32_t t = 0; t < l && t < CLS_INLINE_IDS; ++t) out.cls_desc[c * 8 + 2 + t] = out.col_ids[o + t];
   }
 }
 

@@ -16,6 +16,8 @@ namespace nimble {
 constexpr uint32_t KMER = 30;
 constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
+constexpr uint32_t NODE_INLINE_BASES = 128;
+constexpr uint32_t CLS_INLINE_IDS = 6;
 
 // shared by host build and device kernels ----------------------------------------------------
 #if defined(__HIPCC__)
@@ -31,6 +33,10 @@ NIMBLE_HD uint64_t mix64(uint64_t x) {
   x *= 0xc4ceb9fe1a85ec53ULL;
   x ^= x >> 33;
   return x;
+}
+// slot of a k-mer in the dictionary: one 64-bit multiply (Fibonacci hashing of a folded key)
+NIMBLE_HD uint64_t kmer_slot(uint64_t km, uint32_t log2_slots) {
+  return ((km ^ (km >> 29)) * 0x9E3779B97F4A7C15ULL) >> (64u - log2_slots);
 }
 // content hash of an equivalence class (ascending ids); streaming form
 NIMBLE_HD uint64_t class_hash_init() { return 0x9E3779B97F4A7C15ULL; }
@@ -56,13 +62,22 @@ struct FlatIndex {
   // exact dictionary k-mer -> (node, offset): slot = {key, node<<32 | offset}; linear probing
   std::vector<uint64_t> ht;  // 2 x u64 per slot
   uint64_t ht_slots = 0;     // power of two
-  // node record: {seq_start (base offset into unitig), len (bases), colour, exts (lext | rext<<4)}
-  std::vector<uint32_t> node_hdr;    // 4 x u32 per node
-  std::vector<uint32_t> node_redge;  // 4 x u32 per node, target node per base
-  std::vector<uint32_t> node_ledge;  // 4 x u32 per node
+  uint32_t ht_log2 = 0;
+  // presence bitmap over the same hash, 4 bits per dictionary slot (one bit per k-mer hash value at
+  // ht_log2 + 2 bits): small enough to stay in L2, it answers most absent-k-mer probes
+  std::vector<uint32_t> bitmap;
+  uint32_t bm_log2 = 0;
+  // node record, one 64-byte line per unitig so that a hop costs one dependent memory level:
+  //   u32[0..3]  = {len (bases), colour, exts (lext | rext<<4), seq_start (base offset into unitig)}
+  //   u32[4..7]  = right-edge target node per base
+  //   u32[8..15] = the first 128 bases, 4 x u64 (low word first), base i at word i>>5, bits 62-2*(i&31)
+  std::vector<uint32_t> node_rec;    // 16 x u32 per node
+  std::vector<uint32_t> node_ledge;  // 4 x u32 per node (left extension only)
   std::vector<uint64_t> unitig;      // 2-bit packed, base i at word i>>5, bits 62-2*(i&31)
   std::vector<uint32_t> col_off;     // CSR over static classes, n_colours+1
   std::vector<uint32_t> col_ids;
+  // class descriptor, 32 bytes: {len, off, ids[0..5]} -- classes of up to 6 rows need no second load
+  std::vector<uint32_t> cls_desc;    // 8 x u32 per class
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };
 

@@ -18,13 +18,14 @@ constexpr uint32_t R_TODO = 255;  // prefilter verdict "go on to the walk"
 struct DevIndex {
   const uint4 *ht;          // {key lo, key hi, offset, node}
   uint64_t ht_mask;
-  const uint4 *node_hdr;    // {seq_start, len, colour, exts}
-  const uint4 *node_redge;  // target node per base
+  uint32_t ht_log2;
+  const uint32_t *bitmap;   // presence filter: bit kmer_slot(km, bm_log2)
+  uint32_t bm_log2;
+  const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;
   // class table: static colour classes first, device-interned intersections appended
-  uint32_t *cls_off;
-  uint32_t *cls_len;
+  uint4 *cls_desc;          // 2 x uint4 per class: {len, off, id0, id1} {id2..id5}
   uint32_t *cls_ids;
   uint32_t n_static;
   uint32_t cls_cap;       // capacity in classes
@@ -64,7 +65,7 @@ struct CallBuffers {
   uint64_t *hist_cnt;
   uint64_t hist_mask;
   // [0..7] = counters of nimble_call_counters, [8]=scratch used [9]=unresolved interns
-  // [10]=error flags [11]=histogram entries (compaction)
+  // [10]=error flags [11]=histogram entries (compaction) [12]=align tile counter
   uint64_t *state;
 };
 

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
 // ---------------------------------------------------------------------------------------------
 // k_align helpers
 // ---------------------------------------------------------------------------------------------
+constexpr int PROBE_BATCH = 8;  // seed positions screened per round after the first miss
+
 struct Lane {
   const uint64_t *rd;  // LDS column holding the packed key (stride ALIGN_BLOCK words)
   uint32_t *lc;        // LDS column of visited colours (stride ALIGN_BLOCK)
@@ -151,10 +153,27 @@ struct Lane {
   uint32_t n_cols, last_col, walk_nodes;
   uint32_t probes, nodes;
   uint64_t entries;
-  const uint32_t *cls_len;
+  const uint4 *cls_desc;
   int want_counters;
   uint32_t overflow;
 };
+
+// one unitig: header, right edges and the first 128 bases, all from one 64-byte line
+struct NodeRec {
+  uint4 h;   // {len, colour, exts, seq_start}
+  uint4 re;  // right-edge targets
+  uint4 s0, s1;
+};
+__device__ __forceinline__ NodeRec load_node(const DevIndex &ix, uint32_t node) {
+  const uint4 *p = ix.node_rec + (size_t)node * 4;
+  NodeRec r;
+  r.h = p[0];
+  r.re = p[1];
+  r.s0 = p[2];
+  r.s1 = p[3];
+  return r;
+}
+__device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
 // nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
 __device__ __forceinline__ uint64_t lds_bits(const uint64_t *rd, uint32_t pos, uint32_t nb) {
@@ -173,33 +192,102 @@ __device__ __forceinline__ uint64_t g_bits(const uint64_t *__restrict__ u, uint6
   uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
   return x >> (64u - 2u * nb);
 }
+// nb bases of a unitig at node-relative position pos: from the record while inside its 128 inline bases
+__device__ __forceinline__ uint64_t node_bits(const NodeRec &r, const uint64_t *__restrict__ unitig, uint32_t pos,
+                                              uint32_t nb) {
+  if (pos + nb <= NODE_INLINE_BASES) {
+    const uint64_t w0 = u64of(r.s0.x, r.s0.y), w1 = u64of(r.s0.z, r.s0.w);
+    const uint64_t w2 = u64of(r.s1.x, r.s1.y), w3 = u64of(r.s1.z, r.s1.w);
+    const uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
+    const uint64_t hi = w == 0 ? w0 : (w == 1 ? w1 : (w == 2 ? w2 : w3));
+    const uint64_t lo = w == 0 ? w1 : (w == 1 ? w2 : (w == 2 ? w3 : 0ULL));
+    const uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
+    return x >> (64u - 2u * nb);
+  }
+  return g_bits(unitig, (uint64_t)r.h.w + pos, nb);
+}
 __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t b) {
   return b == 0 ? v.x : (b == 1 ? v.y : (b == 2 ? v.z : v.w));
 }
 
-__device__ __forceinline__ bool ht_lookup(const DevIndex &ix, uint64_t km, uint32_t &node, uint32_t &off) {
-  uint64_t h = mix64(km) & ix.ht_mask;
+// finish a probe whose first slot neither matched nor was empty (linear probing, rare)
+// returns node << 32 | offset, or HT_EMPTY when the k-mer is absent (values only: no scratch traffic)
+__device__ __noinline__ uint64_t ht_resolve_slow(const uint4 *__restrict__ ht, uint64_t mask, uint64_t km,
+                                                 uint64_t h) {
   for (;;) {
-    uint4 s = ix.ht[h];
-    uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
-    if (key == km) {
-      off = s.z;
-      node = s.w;
-      return true;
-    }
-    if (key == HT_EMPTY) return false;
-    h = (h + 1) & ix.ht_mask;
+    h = (h + 1) & mask;
+    uint4 s = ht[h];
+    uint64_t key = u64of(s.x, s.y);
+    if (key == km) return u64of(s.z, s.w);
+    if (key == HT_EMPTY) return HT_EMPTY;
   }
 }
 
-// seed search with stride 3 from kmer_pos (positions relative to the mate)
+// seed search with stride 3 from kmer_pos (positions relative to the mate).  The first probe goes alone
+// (it hits for most on-target reads); after a miss PROBE_BATCH independent probes are kept in flight.
 __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
                                            uint32_t last_kmer_pos, uint32_t &node, uint32_t &off) {
-  while (kmer_pos <= last_kmer_pos) {
-    uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
+  if (kmer_pos > last_kmer_pos) return false;
+  {
+    const uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
+    const uint64_t h = kmer_slot(km, ix.ht_log2);
+    const uint4 s = ix.ht[h];
+    const uint64_t key = u64of(s.x, s.y);
     ln.probes++;
-    if (ht_lookup(ix, km, node, off)) return true;
+    if (key == km) { off = s.z; node = s.w; return true; }
+    if (key != HT_EMPTY) {
+      const uint64_t v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
+      if (v != HT_EMPTY) { off = (uint32_t)v; node = (uint32_t)(v >> 32); return true; }
+    }
     kmer_pos += 3;
+  }
+  while (kmer_pos <= last_kmer_pos) {
+    // PROBE_BATCH positions screened through the L2-resident presence bitmap, all loads in flight at once
+    uint32_t word[PROBE_BATCH], bit[PROBE_BATCH];
+#pragma unroll
+    for (int i = 0; i < PROBE_BATCH; ++i) {
+      const uint32_t p = kmer_pos + 3u * i;
+      const uint32_t pc = p <= last_kmer_pos ? p : last_kmer_pos;
+      const uint64_t b = kmer_slot(lds_bits(ln.rd, base0 + pc, KMER), ix.bm_log2);
+      bit[i] = (uint32_t)b & 31u;
+      word[i] = ix.bitmap[b >> 5];
+    }
+    uint32_t maybe = 0;
+#pragma unroll
+    for (int i = 0; i < PROBE_BATCH; ++i) maybe |= ((word[i] >> bit[i]) & 1u) << i;
+    const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
+    bool found = false;
+    uint32_t fpos = 0;
+#pragma unroll
+    for (int i = 0; i < PROBE_BATCH; ++i) {
+      if (!found && 3u * i <= valid) {
+        ln.probes++;
+        if ((maybe >> i) & 1u) {  // rare after a first miss: bitmap false positive or a real seed
+          const uint32_t p = kmer_pos + 3u * i;
+          const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
+          const uint64_t h = kmer_slot(km, ix.ht_log2);
+          const uint4 sl = ix.ht[h];
+          const uint64_t key = u64of(sl.x, sl.y);
+          uint64_t v = u64of(sl.z, sl.w);
+          bool hit = key == km;
+          if (!hit && key != HT_EMPTY) {
+            v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
+            hit = v != HT_EMPTY;
+          }
+          if (hit) {
+            found = true;
+            fpos = p;
+            off = (uint32_t)v;
+            node = (uint32_t)(v >> 32);
+          }
+        }
+      }
+    }
+    if (found) {
+      kmer_pos = fpos;
+      return true;
+    }
+    kmer_pos += 3u * PROBE_BATCH;
   }
   return false;
 }
@@ -207,7 +295,7 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
 __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour) {
   ln.nodes++;
   ln.walk_nodes++;
-  if (ln.want_counters) ln.entries += ln.cls_len[colour];
+  if (ln.want_counters) ln.entries += ln.cls_desc[(size_t)colour * 2].x;
   if (ln.n_cols && colour == ln.last_col) return;  // intersection is idempotent
   uint32_t j = ln.n_cols;
   ln.last_col = colour;
@@ -225,16 +313,16 @@ __device__ __forceinline__ uint32_t get_col(const Lane &ln, uint32_t j) {
   return j < LDS_COLS ? ln.lc[j * ALIGN_BLOCK] : ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes];
 }
 
-// compare n bases forward: key[rpos + i] vs unitig[upos + i].  Returns the bases accepted; a base that
-// takes this node's mismatch count above `allowed` stops the compare and is not accepted.
-__device__ __forceinline__ uint32_t cmp_fwd(const Lane &ln, const uint64_t *__restrict__ unitig, uint32_t rpos,
-                                            uint64_t upos, uint32_t n, uint32_t allowed, uint32_t &mism,
-                                            bool &premature) {
+// compare n bases forward: key[rpos + i] vs unitig[upos + i] (upos node-relative).  Returns the bases
+// accepted; a base that takes this node's mismatch count above `allowed` stops the compare, unaccepted.
+__device__ __forceinline__ uint32_t cmp_fwd(const Lane &ln, const NodeRec &nr, const uint64_t *__restrict__ unitig,
+                                            uint32_t rpos, uint32_t upos, uint32_t n, uint32_t allowed,
+                                            uint32_t &mism, bool &premature) {
   uint32_t matched = 0, seen = 0;
   premature = false;
   while (matched < n) {
     uint32_t c = n - matched < 32u ? n - matched : 32u;
-    uint64_t x = lds_bits(ln.rd, rpos + matched, c) ^ g_bits(unitig, upos + matched, c);
+    uint64_t x = lds_bits(ln.rd, rpos + matched, c) ^ node_bits(nr, unitig, upos + matched, c);
     uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
     uint32_t cnt = (uint32_t)__popcll(m);
     if (seen + cnt <= allowed) {
@@ -254,14 +342,14 @@ __device__ __forceinline__ uint32_t cmp_fwd(const Lane &ln, const uint64_t *__re
   return matched;
 }
 // compare n bases backward: key[rlast - i] vs unitig[ulast - i]
-__device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const uint64_t *__restrict__ unitig, uint32_t rlast,
-                                            uint64_t ulast, uint32_t n, uint32_t allowed, uint32_t &mism,
-                                            bool &premature) {
+__device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const NodeRec &nr, const uint64_t *__restrict__ unitig,
+                                            uint32_t rlast, uint32_t ulast, uint32_t n, uint32_t allowed,
+                                            uint32_t &mism, bool &premature) {
   uint32_t matched = 0, seen = 0;
   premature = false;
   while (matched < n) {
     uint32_t c = n - matched < 32u ? n - matched : 32u;
-    uint64_t x = lds_bits(ln.rd, rlast - matched - c + 1u, c) ^ g_bits(unitig, ulast - matched - c + 1u, c);
+    uint64_t x = lds_bits(ln.rd, rlast - matched - c + 1u, c) ^ node_bits(nr, unitig, ulast - matched - c + 1u, c);
     uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
     uint32_t cnt = (uint32_t)__popcll(m);
     if (seen + cnt <= allowed) {
@@ -299,20 +387,20 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
     uint32_t pnode = node;
     uint32_t poff = koff > 0 ? koff - 1 : 0;
     for (;;) {
-      uint4 hdr = ix.node_hdr[pnode];
+      NodeRec nr = load_node(ix, pnode);
       uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
       bool prem;
-      uint32_t matched = cmp_bwd(ln, ix.unitig, base0 + last_pos, (uint64_t)hdr.x + poff, n, allowed, mm, prem);
+      uint32_t matched = cmp_bwd(ln, nr, ix.unitig, base0 + last_pos, poff, n, allowed, mm, prem);
       cov += matched;
       if (last_pos + 1 - matched == 0 || prem) break;
       last_pos -= matched;
       uint32_t nbase = lds_base(ln.rd, base0 + last_pos);
-      if (hdr.w & (1u << nbase)) {
+      if (nr.h.z & (1u << nbase)) {
         uint4 le = ix.node_ledge[pnode];
         pnode = sel4(le, nbase);
-        uint4 h2 = ix.node_hdr[pnode];
-        poff = h2.y - KMER;
-        push_col(ln, h2.z);
+        uint4 h2 = ix.node_rec[(size_t)pnode * 4];
+        poff = h2.x - KMER;
+        push_col(ln, h2.y);
       } else {
         break;
       }
@@ -320,24 +408,23 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   }
   if (kmer_pos <= last_kmer_pos) {  // forward search (a seed was found)
     for (;;) {
-      uint4 hdr = ix.node_hdr[node];
+      NodeRec nr = load_node(ix, node);
       kmer_pos += KMER;
       cov += KMER;
-      push_col(ln, hdr.z);
+      push_col(ln, nr.h.y);
       uint32_t remaining = L - kmer_pos;
       uint32_t ref_off = koff + KMER;
-      uint32_t informative = hdr.y - ref_off;
+      uint32_t informative = nr.h.x - ref_off;
       uint32_t n = remaining < informative ? remaining : informative;
       bool prem = false;
       uint32_t matched = 0;
-      if (n) matched = cmp_fwd(ln, ix.unitig, base0 + kmer_pos, (uint64_t)hdr.x + ref_off, n, allowed, mm, prem);
+      if (n) matched = cmp_fwd(ln, nr, ix.unitig, base0 + kmer_pos, ref_off, n, allowed, mm, prem);
       cov += matched;
       kmer_pos += matched;
       if (kmer_pos >= L) break;
       uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
-      if (!prem && ((hdr.w >> 4) & (1u << nbase))) {
-        uint4 re = ix.node_redge[node];
-        node = sel4(re, nbase);
+      if (!prem && ((nr.h.z >> 4) & (1u << nbase))) {
+        node = sel4(nr.re, nbase);
         koff = 0;
         kmer_pos -= KMER - 1;
         cov -= KMER - 1;
@@ -353,7 +440,28 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   return true;
 }
 
-__device__ __forceinline__ bool class_contains(const uint32_t *__restrict__ ids, uint32_t len, uint32_t id) {
+// class descriptor access -------------------------------------------------------------------------
+struct ClsDesc {
+  uint4 a, b;  // {len, off, id0, id1} {id2..id5}
+};
+__device__ __forceinline__ ClsDesc load_desc(const DevIndex &ix, uint32_t c) {
+  ClsDesc d;
+  d.a = ix.cls_desc[(size_t)c * 2];
+  d.b = ix.cls_desc[(size_t)c * 2 + 1];
+  return d;
+}
+__device__ __forceinline__ uint32_t desc_id(const ClsDesc &d, uint32_t t) {  // t < CLS_INLINE_IDS
+  return t == 0 ? d.a.z : (t == 1 ? d.a.w : (t == 2 ? d.b.x : (t == 3 ? d.b.y : (t == 4 ? d.b.z : d.b.w))));
+}
+__device__ __forceinline__ bool class_contains(const DevIndex &ix, const ClsDesc &d, uint32_t id) {
+  const uint32_t len = d.a.x;
+  if (len <= CLS_INLINE_IDS) {
+    bool f = false;
+#pragma unroll
+    for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t) f |= (t < len) & (desc_id(d, t) == id);
+    return f;
+  }
+  const uint32_t *__restrict__ ids = ix.cls_ids + d.a.y;
   uint32_t lo = 0, hi = len;
   while (lo < hi) {
     uint32_t mid = (lo + hi) >> 1;
@@ -369,29 +477,52 @@ __device__ __forceinline__ bool class_contains(const uint32_t *__restrict__ ids,
 __device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t &best_col, uint32_t &best_len,
                                    uint64_t &hash, uint32_t *out) {
   uint32_t best = get_col(ln, 0);
-  uint32_t bl = ix.cls_len[best];
+  uint32_t bl = ix.cls_desc[(size_t)best * 2].x;
   for (uint32_t j = 1; j < ln.n_cols; ++j) {
     uint32_t c = get_col(ln, j);
-    uint32_t l = ix.cls_len[c];
+    uint32_t l = ix.cls_desc[(size_t)c * 2].x;
     if (l < bl) { best = c; bl = l; }
   }
   best_col = best;
   best_len = bl;
-  const uint32_t *bids = ix.cls_ids + ix.cls_off[best];
+  const ClsDesc bd = load_desc(ix, best);
   uint32_t count = 0;
   uint64_t h = class_hash_init();
-  for (uint32_t t = 0; t < bl; ++t) {
-    uint32_t id = bids[t];
-    bool ok = true;
-    for (uint32_t j = 0; j < ln.n_cols; ++j) {
+  if (bl <= CLS_INLINE_IDS) {
+    // small base class: survivors tracked in a bit mask, every other colour visited once
+    uint32_t alive = (1u << bl) - 1u;
+    for (uint32_t j = 0; j < ln.n_cols && alive; ++j) {
       uint32_t c = get_col(ln, j);
       if (c == best) continue;
-      if (!class_contains(ix.cls_ids + ix.cls_off[c], ix.cls_len[c], id)) { ok = false; break; }
+      const ClsDesc od = load_desc(ix, c);
+#pragma unroll
+      for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t)
+        if ((alive >> t) & 1u)
+          if (!class_contains(ix, od, desc_id(bd, t))) alive &= ~(1u << t);
     }
-    if (ok) {
-      if (out) out[count] = id;
-      h = class_hash_step(h, id);
-      ++count;
+#pragma unroll
+    for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t)
+      if ((alive >> t) & 1u) {
+        uint32_t id = desc_id(bd, t);
+        if (out) out[count] = id;
+        h = class_hash_step(h, id);
+        ++count;
+      }
+  } else {
+    const uint32_t *bids = ix.cls_ids + bd.a.y;
+    for (uint32_t t = 0; t < bl; ++t) {
+      uint32_t id = bids[t];
+      bool ok = true;
+      for (uint32_t j = 0; j < ln.n_cols; ++j) {
+        uint32_t c = get_col(ln, j);
+        if (c == best) continue;
+        if (!class_contains(ix, load_desc(ix, c), id)) { ok = false; break; }
+      }
+      if (ok) {
+        if (out) out[count] = id;
+        h = class_hash_step(h, id);
+        ++count;
+      }
     }
   }
   hash = class_hash_final(h, count);
@@ -413,7 +544,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
   ln.ws_lanes = cb.ws_lanes;
   ln.ws_rows = cb.ws_rows;
   ln.ws = cb.ws_cols + ((uint64_t)blockIdx.x * ALIGN_BLOCK + tid);
-  ln.cls_len = ix.cls_len;
+  ln.cls_desc = ix.cls_desc;
   ln.want_counters = want_counters;
   ln.probes = ln.nodes = 0;
   ln.entries = 0;
@@ -424,7 +555,17 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
   const int nm = cb.paired ? 2 : 1;
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
 
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // tile slot lives behind the columns in the dynamic region (keeps the extern base 16-byte aligned)
+  unsigned long long &s_tile =
+      *reinterpret_cast<unsigned long long *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) +
+                                              LDS_COLS * ALIGN_BLOCK);
+  for (;;) {
+    // dynamic tile scheduling: tiles differ a lot in cost (off-target reads probe 41 times)
+    __syncthreads();
+    if (tid == 0) s_tile = atomicAdd((unsigned long long *)&cb.state[12], 1ULL);
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    if (tile >= n_tiles) break;
     const uint64_t r = tile * ALIGN_BLOCK + tid;
     const bool active = r < n;
     uint32_t L[2] = {0, 0};
@@ -457,7 +598,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
             uint32_t count;
             if (ln.n_cols == 1) {
               best_col = get_col(ln, 0);
-              best_len = count = ix.cls_len[best_col];
+              best_len = count = ix.cls_desc[(size_t)best_col * 2].x;
             } else {
               count = intersect_cols(ix, ln, best_col, best_len, dhash, nullptr);
             }
@@ -551,9 +692,14 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
         return;
       }
       const uint32_t *src = cb.scratch + cb.dyn_off[m][i];
-      for (uint32_t t = 0; t < len; ++t) ix.cls_ids[off + t] = src[t];
-      ix.cls_off[id] = off;
-      ix.cls_len[id] = len;
+      uint32_t first[CLS_INLINE_IDS] = {0, 0, 0, 0, 0, 0};
+      for (uint32_t t = 0; t < len; ++t) {
+        uint32_t v = src[t];
+        ix.cls_ids[off + t] = v;
+        if (t < CLS_INLINE_IDS) first[t] = v;
+      }
+      ix.cls_desc[(size_t)id * 2] = make_uint4(len, off, first[0], first[1]);
+      ix.cls_desc[(size_t)id * 2 + 1] = make_uint4(first[2], first[3], first[4], first[5]);
       ix.intern[pos] = ((uint64_t)tag << 32) | id;
       cb.dyn_pos[m][i] = (uint32_t)pos;
       return;
@@ -573,10 +719,12 @@ __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
   if (cb.cls[m][i] != CLS_PENDING) return;
   const uint32_t id = (uint32_t)ix.intern[cb.dyn_pos[m][i]];
   const uint32_t len = cb.dyn_len[m][i];
-  bool same = id < ix.cls_cap && ix.cls_len[id] == len;
+  uint4 d0 = make_uint4(0, 0, 0, 0);
+  if (id < ix.cls_cap) d0 = ix.cls_desc[(size_t)id * 2];
+  bool same = id < ix.cls_cap && d0.x == len;
   if (same) {
     const uint32_t *a = cb.scratch + cb.dyn_off[m][i];
-    const uint32_t *b = ix.cls_ids + ix.cls_off[id];
+    const uint32_t *b = ix.cls_ids + d0.y;
     for (uint32_t t = 0; t < len; ++t)
       if (a[t] != b[t]) { same = false; break; }
   }
@@ -709,8 +857,22 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                   int want_counters) {
   if (cb.n == 0) return;
   uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  uint32_t grid = (uint32_t)(tiles < (uint64_t)ALIGN_GRID ? tiles : (uint64_t)ALIGN_GRID);
-  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4;
+  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + 16;
+  // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
+  // empty round); tiles are handed out through a counter
+  static int resident_cache[64] = {0};
+  int key = (int)(lds / 2048) & 63;
+  if (resident_cache[key] == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align, ALIGN_BLOCK, lds) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    if (cus < 1) cus = 256;
+    int g = per_cu * cus;
+    resident_cache[key] = g > ALIGN_GRID ? ALIGN_GRID : g;
+  }
+  uint32_t grid = (uint32_t)(tiles < (uint64_t)resident_cache[key] ? tiles : (uint64_t)resident_cache[key]);
   hipLaunchKernelGGL(k_align, dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb, want_counters);
 }
 
