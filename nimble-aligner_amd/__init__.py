@@ -382,6 +382,31 @@ def _rows(handle):
         L.nimble_rows_free(handle)
 
 
+class RowsHandle:
+    """Owns a nimble_rows result (Vec<(Vec<String>, i32)> on the C++ side)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __len__(self):
+        return int(host_lib().nimble_rows_count(self.h))
+
+    def to_list(self):
+        L = host_lib()
+        out = []
+        for i in range(len(self)):
+            cnt = C.c_int32()
+            out.append((L.nimble_rows_get(self.h, i, C.byref(cnt)).decode().split("\t"), cnt.value))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            host_lib().nimble_rows_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class Library:
     """(AlignFilterConfig, Reference) of reference_library::get_reference_library, plus the device index."""
 
@@ -459,6 +484,16 @@ class Library:
         _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
                                              max(max_len, 1), mem, C.byref(h)))
         return _rows(h)
+
+    def score_call_raw(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST):
+        """score::call that leaves the rows in the C++ result object (no Python list is built): returns a
+        RowsHandle.  Used by bench.py so that the timed step contains no Python-side conversion."""
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+                                             max(max_len or fixed_len, 1), mem, C.byref(h)))
+        return RowsHandle(h)
 
     def score_call_reads(self, reads, mates=None):
         b1, o1 = pack_reads(reads)

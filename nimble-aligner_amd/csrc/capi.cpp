@@ -110,6 +110,14 @@ struct nimble_ctx {
   bool called = false;
   int want_counters = 1;
   uint32_t dyn_before = 0, dyn_after = 0;
+  // arguments of the call in flight (kept so that finish_call can re-enqueue after growing a pool)
+  nimble_align_params prm{};
+  const uint8_t *in_r[2] = {nullptr, nullptr};
+  const uint64_t *in_off[2] = {nullptr, nullptr};
+  uint32_t in_fixed_len = 0, in_max_len = 0;
+  uint64_t dslots = 0;
+  bool finished = true;
+  int attempt = 0;
   std::vector<uint64_t> h_state = std::vector<uint64_t>(16, 0);
   ~nimble_ctx() {
     for (DevBuf *b : {&b_keys, &b_len[0], &b_len[1], &b_hash, &b_pre[0], &b_pre[1], &b_reason[0], &b_reason[1],
@@ -159,6 +167,121 @@ int ensure_plog(nimble_ctx *c, uint32_t max_len) {
 int fetch_state(nimble_ctx *c) {
   HIPCHK(hipMemcpyAsync(c->h_state.data(), c->b_state.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return NIMBLE_OK;
+}
+
+// histogram compaction into the context's output arrays (entry count lands in state[11])
+int enqueue_compact(nimble_ctx *c) {
+  const uint64_t slots = c->hist_slots;
+  int rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
+  if (!rc) rc = c->b_out_c2.ensure(slots * 4, &c->bytes);
+  if (!rc) rc = c->b_out_cnt.ensure(slots * 8, &c->bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, c->stream));
+  launch_hist_compact(c->stream, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(),
+                      c->b_out_cnt.as<uint64_t>(), slots);
+  return NIMBLE_OK;
+}
+
+// Enqueue the whole launch sequence of one call on the context's stream; nothing here waits for the GPU.
+int enqueue_call(nimble_ctx *c) {
+  hipStream_t s = c->stream;
+  CallBuffers &cb = c->cb;
+  const size_t nn = std::max<uint64_t>(cb.n, 1);
+  HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
+  HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
+  HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
+  HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+  if (!cb.paired) HIPCHK(hipMemsetAsync(c->b_len[1].p, 0, nn * 4, s));
+  HIPCHK(hipEventRecord(c->ev[0], s));
+  launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
+              c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
+  HIPCHK(hipEventRecord(c->ev[1], s));
+  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters);
+  HIPCHK(hipEventRecord(c->ev[2], s));
+  // class interning, round 0: claim, then verify behind the kernel boundary.  Tag collisions (practically
+  // never) leave reads unresolved; finish_call() then runs further rounds and redoes dedup + count.
+  launch_intern_claim(s, c->ix->dev, cb, 0);
+  launch_intern_verify(s, c->ix->dev, cb);
+  HIPCHK(hipEventRecord(c->ev[3], s));
+  launch_dedup(s, c->prm, cb);
+  HIPCHK(hipEventRecord(c->ev[4], s));
+  launch_count(s, cb);
+  HIPCHK(hipEventRecord(c->ev[5], s));
+  int rc = enqueue_compact(c);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return NIMBLE_OK;
+}
+
+int redo_dedup_count(nimble_ctx *c) {
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
+  HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
+  HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 10, 0, 8, s));
+  HIPCHK(hipEventRecord(c->ev[3], s));
+  launch_dedup(s, c->prm, c->cb);
+  HIPCHK(hipEventRecord(c->ev[4], s));
+  launch_count(s, c->cb);
+  HIPCHK(hipEventRecord(c->ev[5], s));
+  return enqueue_compact(c);
+}
+
+// Wait for the call and resolve the rare conditions that need host intervention (pool growth, intern tag
+// collisions, histogram growth).  Idempotent; every getter goes through here.
+int finish_call(nimble_ctx *c) {
+  if (c->finished) return NIMBLE_OK;
+  for (;;) {
+    int rc = fetch_state(c);
+    if (rc) return rc;
+    const uint64_t err = c->h_state[10];
+    if (err & ERR_SCRATCH) {
+      if (c->attempt >= 3 || c->scratch_cap >= 0xFFFFFF00ULL)
+        return fail(NIMBLE_E_OVERFLOW, "class scratch pool overflow (raise NIMBLE_SCRATCH_PER_READ)");
+      c->attempt++;
+      c->scratch_cap = std::min<uint64_t>(c->scratch_cap * 4, 0xFFFFFF00ULL);
+      rc = c->b_scratch.ensure(c->scratch_cap * 4, &c->bytes);
+      if (rc) return rc;
+      c->cb.scratch = c->b_scratch.as<uint32_t>();
+      c->cb.scratch_cap = (uint32_t)c->scratch_cap;
+      rc = enqueue_call(c);
+      if (rc) return rc;
+      continue;
+    }
+    if (err & ERR_CLASS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class table full (raise NIMBLE_DYN_CLASSES)");
+    if (err & ERR_IDS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class id pool full (raise NIMBLE_DYN_IDS)");
+    if (c->h_state[9] != 0) {  // unresolved interns: probe further, then redo the stages that used class ids
+      for (int round = 1; c->h_state[9] != 0; ++round) {
+        if (round > 64) return fail(NIMBLE_E_INTERNAL, "class interning did not converge");
+        HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 9, 0, 8, c->stream));
+        launch_intern_claim(c->stream, c->ix->dev, c->cb, round);
+        launch_intern_verify(c->stream, c->ix->dev, c->cb);
+        rc = fetch_state(c);
+        if (rc) return rc;
+        if (c->h_state[10] & (ERR_CLASS_CAP | ERR_IDS_CAP))
+          return fail(NIMBLE_E_OVERFLOW, "dynamic class table full (raise NIMBLE_DYN_CLASSES / NIMBLE_DYN_IDS)");
+      }
+      rc = redo_dedup_count(c);
+      if (rc) return rc;
+      continue;
+    }
+    if (err & ERR_HIST) {
+      if (c->hist_slots >= (1ULL << 30)) return fail(NIMBLE_E_OVERFLOW, "histogram table overflow");
+      c->hist_slots *= 16;
+      rc = c->b_hist_keys.ensure(c->hist_slots * 8, &c->bytes);
+      if (!rc) rc = c->b_hist_cnt.ensure(c->hist_slots * 8, &c->bytes);
+      if (rc) return rc;
+      c->cb.hist_keys = c->b_hist_keys.as<uint64_t>();
+      c->cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
+      c->cb.hist_mask = c->hist_slots - 1;
+      rc = redo_dedup_count(c);
+      if (rc) return rc;
+      continue;
+    }
+    break;
+  }
+  c->finished = true;
   return NIMBLE_OK;
 }
 
@@ -502,83 +625,24 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   HIPCHK(hipStreamSynchronize(s));
   c->dyn_before = dst[0];
 
-  nimble_align_params prm = *p;
-  if (prm.min_read_length == 0) prm.min_read_length = 40;
-
-  for (int attempt = 0;; ++attempt) {
-    HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
-    HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, dslots * 8, s));
-    HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
-    HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
-    if (!paired) HIPCHK(hipMemsetAsync(c->b_len[1].p, 0, nn * 4, s));
-
-    HIPCHK(hipEventRecord(c->ev[0], s));
-    launch_pack(s, d_r[0], d_off[0], d_r[1], d_off[1], fixed_len, max_len, prm.min_read_length,
-                c->b_plog.as<double>(), c->plog_max_len, cb);
-    HIPCHK(hipEventRecord(c->ev[1], s));
-    launch_align(s, ix->dev, prm, cb, c->want_counters);
-    HIPCHK(hipEventRecord(c->ev[2], s));
-    // intern rounds: claim, then verify after the kernel boundary; repeat while tag collisions remain
-    bool retry = false;
-    for (int round = 0;; ++round) {
-      launch_intern_claim(s, ix->dev, cb, round);
-      launch_intern_verify(s, ix->dev, cb);
-      rc = fetch_state(c);
-      if (rc) return rc;
-      uint64_t err = c->h_state[10];
-      if (err & ERR_SCRATCH) {
-        if (attempt >= 3 || c->scratch_cap >= 0xFFFFFF00ULL)
-          return fail(NIMBLE_E_OVERFLOW, "class scratch pool overflow (raise NIMBLE_SCRATCH_PER_READ)");
-        c->scratch_cap = std::min<uint64_t>(c->scratch_cap * 4, 0xFFFFFF00ULL);
-        rc = c->b_scratch.ensure(c->scratch_cap * 4, &c->bytes);
-        if (rc) return rc;
-        cb.scratch = c->b_scratch.as<uint32_t>();
-        cb.scratch_cap = (uint32_t)c->scratch_cap;
-        retry = true;
-        break;
-      }
-      if (err & ERR_CLASS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class table full (raise NIMBLE_DYN_CLASSES)");
-      if (err & ERR_IDS_CAP) return fail(NIMBLE_E_OVERFLOW, "dynamic class id pool full (raise NIMBLE_DYN_IDS)");
-      if (c->h_state[9] == 0) break;
-      if (round > 64) return fail(NIMBLE_E_INTERNAL, "class interning did not converge");
-      HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 9, 0, 8, s));
-    }
-    if (retry) continue;
-    HIPCHK(hipEventRecord(c->ev[3], s));
-    launch_dedup(s, prm, cb);
-    HIPCHK(hipEventRecord(c->ev[4], s));
-    launch_count(s, cb);
-    HIPCHK(hipEventRecord(c->ev[5], s));
-    break;
-  }
-  HIPCHK(hipGetLastError());
+  c->prm = *p;
+  if (c->prm.min_read_length == 0) c->prm.min_read_length = 40;
+  c->in_r[0] = d_r[0];
+  c->in_r[1] = d_r[1];
+  c->in_off[0] = d_off[0];
+  c->in_off[1] = d_off[1];
+  c->in_fixed_len = fixed_len;
+  c->in_max_len = max_len;
+  c->dslots = dslots;
+  c->finished = false;
+  c->attempt = 0;
+  rc = enqueue_call(c);
+  if (rc) return rc;
   c->called = true;
   return NIMBLE_OK;
 }
 
-static int finish_count_stage(nimble_ctx *c) {
-  // histogram table overflow is detected after the fact; grow and redo the count stage
-  for (int attempt = 0;; ++attempt) {
-    int rc = fetch_state(c);
-    if (rc) return rc;
-    if (!(c->h_state[10] & ERR_HIST)) return NIMBLE_OK;
-    if (attempt >= 4) return fail(NIMBLE_E_OVERFLOW, "histogram table overflow");
-    c->hist_slots *= 16;
-    rc = c->b_hist_keys.ensure(c->hist_slots * 8, &c->bytes);
-    if (rc) return rc;
-    rc = c->b_hist_cnt.ensure(c->hist_slots * 8, &c->bytes);
-    if (rc) return rc;
-    CallBuffers &cb = c->cb;
-    cb.hist_keys = c->b_hist_keys.as<uint64_t>();
-    cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
-    cb.hist_mask = c->hist_slots - 1;
-    hipStream_t s = c->stream;
-    HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
-    HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
-    HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 10, 0, 8, s));
-    launch_count(s, cb);
-  }
-}
+static int finish_count_stage(nimble_ctx *c) { return finish_call(c); }
 
 int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count, uint64_t cap,
                      uint64_t *n_entries) {
@@ -586,17 +650,6 @@ int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram: no call has been made on this context");
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = finish_count_stage(c);
-  if (rc) return rc;
-  hipStream_t s = c->stream;
-  const uint64_t slots = c->hist_slots;
-  rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
-  if (!rc) rc = c->b_out_c2.ensure(slots * 4, &c->bytes);
-  if (!rc) rc = c->b_out_cnt.ensure(slots * 8, &c->bytes);
-  if (rc) return rc;
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, s));
-  launch_hist_compact(s, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(), c->b_out_cnt.as<uint64_t>(),
-                      slots);
-  rc = fetch_state(c);
   if (rc) return rc;
   const uint64_t ne = c->h_state[11];
   *n_entries = ne;

@@ -12,7 +12,10 @@
 // `ends_with("rev")` / trim_end_matches parsing (align.rs:276-285), strip_suffix("§rev")
 // (align.rs:149,164), first-match `unmap` (align.rs:851-864), the discarded `unique()` (align.rs:794).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_set>
 
@@ -293,6 +296,48 @@ std::unique_ptr<PseudoAligner> PseudoAligner::build_index(const std::vector<std:
   return pa;
 }
 
+struct PseudoAligner::CoercionMemo {
+  // exact copies of everything Coercer reads
+  size_t group_on = 0, name_idx = 0;
+  std::string group_header;
+  std::vector<std::string> names, groups;
+  LibraryChemistry strand = LibraryChemistry::None;
+  IntersectLevel level = IntersectLevel::NoIntersect;
+  size_t discard_multi_hits = 0, max_hits = 0;
+  std::unique_ptr<Coercer> coercer;
+  // (class R1 << 32 | class R2) -> index into `callsets` (or -1 when the pair is triaged away)
+  std::unordered_map<uint64_t, int32_t> pairs;
+  std::vector<std::vector<std::string>> callsets;
+  std::map<std::vector<std::string>, int32_t> callset_ids;
+  std::vector<int32_t> sorted;  // callset ids in Vec<String> order; rebuilt when callsets grew
+  std::vector<int64_t> counts;  // scratch, one slot per callset
+
+  bool matches(const reference_library::Reference &r, const AlignFilterConfig &c) const {
+    return group_on == r.group_on && name_idx == r.sequence_name_idx && strand == c.strand_filter &&
+           level == c.intersect_level && discard_multi_hits == c.discard_multi_hits &&
+           max_hits == c.max_hits_to_report && group_header == r.headers.at(r.group_on) &&
+           names == r.columns.at(r.sequence_name_idx) && groups == r.columns.at(r.group_on);
+  }
+};
+
+PseudoAligner::CoercionMemo &PseudoAligner::memo_for(const reference_library::Reference &r,
+                                                     const AlignFilterConfig &c) {
+  if (!memo_ || !memo_->matches(r, c)) {
+    memo_.reset(new CoercionMemo());
+    memo_->group_on = r.group_on;
+    memo_->name_idx = r.sequence_name_idx;
+    memo_->group_header = r.headers.at(r.group_on);
+    memo_->names = r.columns.at(r.sequence_name_idx);
+    memo_->groups = r.columns.at(r.group_on);
+    memo_->strand = c.strand_filter;
+    memo_->level = c.intersect_level;
+    memo_->discard_multi_hits = c.discard_multi_hits;
+    memo_->max_hits = c.max_hits_to_report;
+    memo_->coercer.reset(new Coercer(r, c));
+  }
+  return *memo_;
+}
+
 PseudoAligner::~PseudoAligner() {
   if (ctx_) nimble_ctx_free(ctx_);
   if (index_) nimble_index_free(index_);
@@ -313,6 +358,9 @@ CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligne
                      bool want_per_read) {
   if (mates && mates->n != seqs.n)
     throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  static const bool timing = getenv("NIMBLE_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
   nimble_align_params p;
   memset(&p, 0, sizeof p);
   p.score_percent = config.score_percent;
@@ -324,28 +372,60 @@ CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligne
   p.min_read_length = (uint32_t)MIN_READ_LENGTH;
   uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
   if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
+  // the device call is asynchronous: the coercion tables are (re)built while the GPU works
   check_rc(nimble_call(index.ctx(), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                        mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
                        seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
            "nimble_call");
+  PseudoAligner::CoercionMemo &memo = index.memo_for(reference, config);
+  auto t1 = now();
   uint64_t ne = 0;
   check_rc(nimble_histogram(index.ctx(), nullptr, nullptr, nullptr, 0, &ne), "nimble_histogram");
   std::vector<uint32_t> c1(ne), c2(ne);
   std::vector<uint64_t> cnt(ne);
   if (ne) check_rc(nimble_histogram(index.ctx(), c1.data(), c2.data(), cnt.data(), ne, &ne), "nimble_histogram");
 
-  Coercer coercer(reference, config);
-  std::map<std::vector<std::string>, int64_t> results;  // the `results` HashMap of align.rs:434
+  auto t2 = now();
+  // the `results` HashMap of align.rs:434, as dense counts over the memoised callsets
   static const std::vector<uint32_t> empty;
+  memo.counts.assign(memo.callsets.size(), 0);
   for (uint64_t e = 0; e < ne; ++e) {
-    bool has1 = c1[e] != NIMBLE_CLASS_NONE, has2 = c2[e] != NIMBLE_CLASS_NONE;
-    FilterReason triage;
-    std::vector<std::string> callset = coercer.coerce(has1, has1 ? index.eq_class(c1[e]) : empty, has2,
-                                                      has2 ? index.eq_class(c2[e]) : empty, triage);
-    if (!callset.empty()) results[callset] += (int64_t)cnt[e];
+    const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
+    auto it = memo.pairs.find(key);
+    if (it == memo.pairs.end()) {
+      bool has1 = c1[e] != NIMBLE_CLASS_NONE, has2 = c2[e] != NIMBLE_CLASS_NONE;
+      FilterReason triage;
+      std::vector<std::string> callset = memo.coercer->coerce(has1, has1 ? index.eq_class(c1[e]) : empty, has2,
+                                                              has2 ? index.eq_class(c2[e]) : empty, triage);
+      int32_t id = -1;
+      if (!callset.empty()) {
+        auto ins = memo.callset_ids.emplace(callset, (int32_t)memo.callsets.size());
+        if (ins.second) {
+          memo.callsets.push_back(std::move(callset));
+          memo.counts.push_back(0);
+          memo.sorted.clear();
+        }
+        id = ins.first->second;
+      }
+      it = memo.pairs.emplace(key, id).first;
+    }
+    if (it->second >= 0) memo.counts[(size_t)it->second] += (int64_t)cnt[e];
+  }
+  auto t3 = now();
+  if (memo.sorted.size() != memo.callsets.size()) {
+    memo.sorted.clear();
+    for (auto &kv : memo.callset_ids) memo.sorted.push_back(kv.second);  // std::map order == Vec<String> order
   }
   CallOutput out;
-  for (auto &kv : results) out.rows.emplace_back(kv.first, (int32_t)kv.second);
+  for (int32_t id : memo.sorted)
+    if (memo.counts[(size_t)id]) out.rows.emplace_back(memo.callsets[(size_t)id], (int32_t)memo.counts[(size_t)id]);
+  if (timing) {
+    auto t4 = now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[nimble host] enqueue + coercion tables %.3f ms, wait + histogram %.3f ms, coerce %llu pairs "
+                    "%.3f ms, rows %.3f ms\n",
+            ms(t0, t1), ms(t1, t2), (unsigned long long)ne, ms(t2, t3), ms(t3, t4));
+  }
   if (want_per_read) {
     out.per_read.resize(seqs.n);
     std::vector<int32_t> r[2], s[2];

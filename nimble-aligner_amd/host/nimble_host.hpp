@@ -110,6 +110,8 @@ int natural_lexical_cmp(const std::string &a, const std::string &b);
 
 namespace align {
 
+class Coercer;
+
 // Replaces `PseudoAligner` (src/align.rs:21): the device-resident index plus a calling context.
 class PseudoAligner {
  public:
@@ -121,11 +123,18 @@ class PseudoAligner {
   nimble_ctx *ctx() const { return ctx_; }
   const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
 
+  // Coercion memo: class ids are stable for the life of the index, and the coercion of a class pair depends
+  // only on (Reference names / groups, the coercion part of the config).  The memo is keyed by an exact
+  // copy of those inputs and is dropped as soon as a call arrives with different ones.
+  struct CoercionMemo;
+  CoercionMemo &memo_for(const reference_library::Reference &reference, const AlignFilterConfig &config);
+
  private:
   PseudoAligner() = default;
   nimble_index *index_ = nullptr;
   nimble_ctx *ctx_ = nullptr;
   std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
+  std::shared_ptr<CoercionMemo> memo_;
 };
 
 // A batch of reads in memory: concatenated ASCII bases + n+1 offsets (what the reference's boxed
