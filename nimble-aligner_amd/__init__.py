@@ -15,7 +15,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB_PATH = os.path.join(LIB_DIR, "libnimble_hip.so")
+# NIMBLE_HIP_LIB selects another build of the same library (A/B runs of kernel variants)
+HIP_LIB_PATH = os.environ.get("NIMBLE_HIP_LIB") or os.path.join(LIB_DIR, "libnimble_hip.so")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_host.so")
 
 CLASS_NONE = 0xFFFFFFFF

@@ -81,12 +81,13 @@ struct DevBuf {
 struct nimble_index {
   int device = 0;
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_ids, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
-    for (DevBuf *b : {&b_ht, &b_bitmap, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_ids, &b_intern, &b_dyn_state})
+    for (DevBuf *b : {&b_ht, &b_bitmap, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_intern,
+                      &b_dyn_state})
       b->release();
   }
 };
@@ -348,7 +349,9 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   up(ix->b_unitig, fi.unitig);
   std::vector<uint32_t> len(fi.n_colours);
   for (size_t c = 0; c < fi.n_colours; ++c) len[c] = fi.col_off[c + 1] - fi.col_off[c];
-  up(ix->b_cls_desc, fi.cls_desc, cls_cap * 8);
+  up(ix->b_cls_desc, fi.cls_desc, cls_cap * 4);
+  std::vector<uint32_t> coff(fi.col_off.begin(), fi.col_off.end() - 1);
+  up(ix->b_cls_off, coff, cls_cap);
   up(ix->b_cls_ids, fi.col_ids, ids_cap);
   // intern table seeded with the static classes, so that an intersection equal to a k-mer colour
   // resolves to that colour's id (class ids are canonical by content)
@@ -381,6 +384,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
   d.cls_desc = ix->b_cls_desc.as<uint4>();
+  d.cls_off = ix->b_cls_off.as<uint32_t>();
   d.cls_ids = ix->b_cls_ids.as<uint32_t>();
   d.n_static = (uint32_t)fi.n_colours;
   d.cls_cap = (uint32_t)cls_cap;
@@ -442,9 +446,10 @@ int nimble_class_get(const nimble_index *ix, uint32_t id, uint32_t *ids, uint32_
   uint32_t st[4];
   HIPCHK(hipMemcpy(st, ix->b_dyn_state.p, sizeof(st), hipMemcpyDeviceToHost));
   if (id >= st[0] || id >= ix->dev.cls_cap) return fail(NIMBLE_E_INVALID, "nimble_class_get: unknown class id");
-  uint32_t desc[2] = {0, 0};
-  HIPCHK(hipMemcpy(desc, ix->dev.cls_desc + (size_t)id * 2, 8, hipMemcpyDeviceToHost));
-  const uint32_t l = desc[0], o = desc[1];
+  uint32_t desc0 = 0, o = 0;
+  HIPCHK(hipMemcpy(&desc0, ix->dev.cls_desc + (size_t)id, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&o, ix->dev.cls_off + id, 4, hipMemcpyDeviceToHost));
+  const uint32_t l = desc0 & ~CLS_MASK_FLAG;
   *len = l;
   if (ids && l && cap)
     HIPCHK(hipMemcpy(ids, ix->dev.cls_ids + o, sizeof(uint32_t) * std::min(l, cap), hipMemcpyDeviceToHost));

@@ -198,6 +198,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   uint64_t slots = 64;
   uint32_t log2_slots = 6;
   while (slots < 2 * (uint64_t)n + 2) { slots <<= 1; ++log2_slots; }
+  if (log2_slots + 2 > 32) throw std::runtime_error("index build: too many k-mers for the 32-bit slot hash");
   out.ht_slots = slots;
   out.ht_log2 = log2_slots;
   out.ht.assign(slots * 2, 0);
@@ -215,12 +216,10 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     out.bitmap[b >> 5] |= 1u << (b & 31);
   }
   // 7. class descriptors
-  out.cls_desc.assign(out.n_colours * 8, 0);
+  out.cls_desc.assign(out.n_colours * 4, 0);
   for (size_t c = 0; c < out.n_colours; ++c) {
     uint32_t o = out.col_off[c], l = out.col_off[c + 1] - o;
-    out.cls_desc[c * 8 + 0] = l;
-    out.cls_desc[c * 8 + 1] = o;
-    for (uint32_t t = 0; t < l && t < CLS_INLINE_IDS; ++t) out.cls_desc[c * 8 + 2 + t] = out.col_ids[o + t];
+    make_class_desc(out.col_ids.data() + o, l, &out.cls_desc[c * 4]);
   }
 }
 

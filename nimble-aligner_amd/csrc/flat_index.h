@@ -17,7 +17,8 @@ constexpr uint32_t KMER = 30;
 constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
 constexpr uint32_t NODE_INLINE_BASES = 128;
-constexpr uint32_t CLS_INLINE_IDS = 6;
+constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
+constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;  // set in the descriptor's len word when the mask form is valid
 
 // shared by host build and device kernels ----------------------------------------------------
 #if defined(__HIPCC__)
@@ -34,9 +35,11 @@ NIMBLE_HD uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
-// slot of a k-mer in the dictionary: one 64-bit multiply (Fibonacci hashing of a folded key)
+// slot of a k-mer in the dictionary / presence bitmap: the 60-bit key folded to 32 bits, one 32-bit
+// multiply (Fibonacci hashing), top log2_slots bits (log2_slots <= 32)
 NIMBLE_HD uint64_t kmer_slot(uint64_t km, uint32_t log2_slots) {
-  return ((km ^ (km >> 29)) * 0x9E3779B97F4A7C15ULL) >> (64u - log2_slots);
+  const uint32_t f = (uint32_t)km ^ (uint32_t)(km >> 29);
+  return (uint64_t)((f * 0x9E3779B1u) >> (32u - log2_slots));
 }
 // content hash of an equivalence class (ascending ids); streaming form
 NIMBLE_HD uint64_t class_hash_init() { return 0x9E3779B97F4A7C15ULL; }
@@ -52,6 +55,23 @@ NIMBLE_HD uint32_t encode_base(uint32_t c) {
   v ^= v >> 1;                 // a->0 c->1 g->2 t->3
   bool ok = (l == 'a') | (l == 'c') | (l == 'g') | (l == 't');
   return ok ? v : 0u;
+}
+
+// descriptor of a class given its ascending ids (host build and device interning share this)
+NIMBLE_HD void make_class_desc(const uint32_t *ids, uint32_t len, uint32_t desc[4]) {
+  desc[0] = len;
+  desc[1] = 0;
+  desc[2] = 0;
+  desc[3] = 0;
+  if (len == 0) return;
+  const uint32_t base = ids[0];
+  if (ids[len - 1] - base >= 64u) return;
+  uint64_t m = 0;
+  for (uint32_t t = 0; t < len; ++t) m |= 1ULL << (ids[t] - base);
+  desc[0] = len | 0x80000000u;
+  desc[1] = base;
+  desc[2] = (uint32_t)m;
+  desc[3] = (uint32_t)(m >> 32);
 }
 
 // intern table slot: high 32 bits = tag (never 0), low 32 bits = class id or INTERN_PENDING
@@ -76,8 +96,11 @@ struct FlatIndex {
   std::vector<uint64_t> unitig;      // 2-bit packed, base i at word i>>5, bits 62-2*(i&31)
   std::vector<uint32_t> col_off;     // CSR over static classes, n_colours+1
   std::vector<uint32_t> col_ids;
-  // class descriptor, 32 bytes: {len, off, ids[0..5]} -- classes of up to 6 rows need no second load
-  std::vector<uint32_t> cls_desc;    // 8 x u32 per class
+  // class descriptor, 16 bytes: {len | CLS_MASK_FLAG, base row, mask lo, mask hi}: bit i of the mask = row
+  // base + i.  Library rows of one gene family are adjacent, so almost every class is local and the
+  // intersection of visited colours is one 16-byte load per colour plus shift/AND.  Classes that span 64
+  // rows or more keep len without the flag and are intersected through the CSR ids.
+  std::vector<uint32_t> cls_desc;    // 4 x u32 per class
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };
 

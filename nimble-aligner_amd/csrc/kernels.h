@@ -25,7 +25,8 @@ struct DevIndex {
   const uint4 *node_ledge;
   const uint64_t *unitig;
   // class table: static colour classes first, device-interned intersections appended
-  uint4 *cls_desc;          // 2 x uint4 per class: {len, off, id0, id1} {id2..id5}
+  uint4 *cls_desc;          // {len | CLS_MASK_FLAG, base, mask lo, mask hi}
+  uint32_t *cls_off;        // offset of the class in cls_ids (CSR form, every class has it)
   uint32_t *cls_ids;
   uint32_t n_static;
   uint32_t cls_cap;       // capacity in classes

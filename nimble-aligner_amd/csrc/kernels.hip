@@ -244,13 +244,26 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
   while (kmer_pos <= last_kmer_pos) {
     // PROBE_BATCH positions screened through the L2-resident presence bitmap, all loads in flight at once
     uint32_t word[PROBE_BATCH], bit[PROBE_BATCH];
+    {
+      // k-mers at stride 3 by rolling: drop 3 bases, append 3 (one LDS window fetch per 8 positions
+      // instead of 8); positions past the end reuse the last valid k-mer and are ignored below
+      const uint32_t span = KMER + 3u * (PROBE_BATCH - 1);  // bases covered by the round: 51
+      const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;  // bases of the mate from kmer_pos on
+      uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
+      // the 21 bases behind the first k-mer, left-aligned in `tail` (zero-filled past the mate's end)
+      const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
+      uint64_t tail = extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
 #pragma unroll
-    for (int i = 0; i < PROBE_BATCH; ++i) {
-      const uint32_t p = kmer_pos + 3u * i;
-      const uint32_t pc = p <= last_kmer_pos ? p : last_kmer_pos;
-      const uint64_t b = kmer_slot(lds_bits(ln.rd, base0 + pc, KMER), ix.bm_log2);
-      bit[i] = (uint32_t)b & 31u;
-      word[i] = ix.bitmap[b >> 5];
+      for (int i = 0; i < PROBE_BATCH; ++i) {
+        const uint64_t b = kmer_slot(km, ix.bm_log2);
+        bit[i] = (uint32_t)b & 31u;
+        word[i] = ix.bitmap[b >> 5];
+        // next k-mer: shift in the next 3 bases of the tail
+        if (i + 1 < PROBE_BATCH) {
+          const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
+          km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
+        }
+      }
     }
     uint32_t maybe = 0;
 #pragma unroll
@@ -295,7 +308,7 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
 __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour) {
   ln.nodes++;
   ln.walk_nodes++;
-  if (ln.want_counters) ln.entries += ln.cls_desc[(size_t)colour * 2].x;
+  if (ln.want_counters) ln.entries += ln.cls_desc[colour].x & ~CLS_MASK_FLAG;
   if (ln.n_cols && colour == ln.last_col) return;  // intersection is idempotent
   uint32_t j = ln.n_cols;
   ln.last_col = colour;
@@ -407,6 +420,10 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
     }
   }
   if (kmer_pos <= last_kmer_pos) {  // forward search (a seed was found)
+#ifdef NIMBLE_ABL_NO_WALK
+    push_col(ln, node);
+    if (false)
+#endif
     for (;;) {
       NodeRec nr = load_node(ix, node);
       kmer_pos += KMER;
@@ -440,90 +457,132 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   return true;
 }
 
-// class descriptor access -------------------------------------------------------------------------
-struct ClsDesc {
-  uint4 a, b;  // {len, off, id0, id1} {id2..id5}
-};
-__device__ __forceinline__ ClsDesc load_desc(const DevIndex &ix, uint32_t c) {
-  ClsDesc d;
-  d.a = ix.cls_desc[(size_t)c * 2];
-  d.b = ix.cls_desc[(size_t)c * 2 + 1];
-  return d;
-}
-__device__ __forceinline__ uint32_t desc_id(const ClsDesc &d, uint32_t t) {  // t < CLS_INLINE_IDS
-  return t == 0 ? d.a.z : (t == 1 ? d.a.w : (t == 2 ? d.b.x : (t == 3 ? d.b.y : (t == 4 ? d.b.z : d.b.w))));
-}
-__device__ __forceinline__ bool class_contains(const DevIndex &ix, const ClsDesc &d, uint32_t id) {
-  const uint32_t len = d.a.x;
-  if (len <= CLS_INLINE_IDS) {
-    bool f = false;
-#pragma unroll
-    for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t) f |= (t < len) & (desc_id(d, t) == id);
-    return f;
-  }
-  const uint32_t *__restrict__ ids = ix.cls_ids + d.a.y;
-  uint32_t lo = 0, hi = len;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    uint32_t v = ids[mid];
-    if (v < id) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo < len && ids[lo] == id;
+// class table access ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t desc_len(const uint4 &d) { return d.x & ~CLS_MASK_FLAG; }
+__device__ __forceinline__ bool desc_is_mask(const uint4 &d) { return (d.x & CLS_MASK_FLAG) != 0; }
+__device__ __forceinline__ uint64_t desc_mask(const uint4 &d) { return u64of(d.z, d.w); }
+
+// mask of class d expressed in the window starting at row `base`
+__device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base) {
+  const uint64_t m = desc_mask(d);
+  const int32_t delta = (int32_t)(d.y - base);
+  if (delta >= 0) return delta < 64 ? (m << delta) : 0ULL;
+  return -delta < 64 ? (m >> (-delta)) : 0ULL;
 }
 
-// nodes_to_eq_class: intersection of the visited colours, smallest class first.
-// Returns the class length; writes ids to `out` when non-null.
+// general form of nodes_to_eq_class (some visited class spans 64 rows or more): smallest class first,
+// membership test of each of its rows in every other visited class.  Everything is passed and returned by
+// value so that the (rare) out-of-line call does not force the caller's state into scratch.
+struct IRes {
+  uint32_t count;
+  uint64_t hash;
+};
+__device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint32_t *cls_off, const uint32_t *cls_ids,
+                                               const uint32_t *lc, const uint32_t *ws, uint32_t ws_lanes,
+                                               uint32_t n_cols, uint32_t best, uint32_t bl, uint32_t *out) {
+  const uint32_t *bids = cls_ids + cls_off[best];
+  uint32_t count = 0;
+  uint64_t h = class_hash_init();
+  for (uint32_t t = 0; t < bl; ++t) {
+    const uint32_t id = bids[t];
+    bool ok = true;
+    for (uint32_t j = 0; j < n_cols && ok; ++j) {
+      const uint32_t c = j < LDS_COLS ? lc[j * ALIGN_BLOCK] : ws[(uint64_t)(j - LDS_COLS) * ws_lanes];
+      if (c == best) continue;
+      const uint4 d = cls_desc[c];
+      if (desc_is_mask(d)) {
+        const uint32_t off = id - d.y;
+        ok = id >= d.y && off < 64u && ((desc_mask(d) >> off) & 1ULL);
+      } else {
+        const uint32_t len = desc_len(d);
+        const uint32_t *__restrict__ ids = cls_ids + cls_off[c];
+        uint32_t lo = 0, hi = len;
+        while (lo < hi) {
+          uint32_t mid = (lo + hi) >> 1;
+          if (ids[mid] < id) lo = mid + 1;
+          else hi = mid;
+        }
+        ok = lo < len && ids[lo] == id;
+      }
+    }
+    if (ok) {
+      if (out) out[count] = id;
+      h = class_hash_step(h, id);
+      ++count;
+    }
+  }
+  IRes r;
+  r.count = count;
+  r.hash = class_hash_final(h, count);
+  return r;
+}
+
+// nodes_to_eq_class: intersection of the visited colours.  Returns the class length, the smallest visited
+// class (best_col / best_len: when the result has that length it *is* that class), the content hash, and
+// writes the ids to `out` when non-null.  Local classes fold as 64-bit masks: one 16-byte load per colour.
+struct MaskRes {  // the result as base + mask (valid when is_mask), normalised so that bit 0 is set
+  bool is_mask;
+  uint32_t base;
+  uint64_t mask;
+};
 __device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t &best_col, uint32_t &best_len,
-                                   uint64_t &hash, uint32_t *out) {
-  uint32_t best = get_col(ln, 0);
-  uint32_t bl = ix.cls_desc[(size_t)best * 2].x;
-  for (uint32_t j = 1; j < ln.n_cols; ++j) {
-    uint32_t c = get_col(ln, j);
-    uint32_t l = ix.cls_desc[(size_t)c * 2].x;
-    if (l < bl) { best = c; bl = l; }
+                                   uint64_t &hash, uint32_t *out, MaskRes &mr) {
+  const uint32_t n = ln.n_cols;
+  uint32_t best = 0, bl = 0xFFFFFFFFu, base = 0;
+  uint64_t acc = ~0ULL;
+  bool all_mask = true;
+  if (n <= LDS_COLS) {
+    // all descriptor loads in flight together
+    uint32_t col[LDS_COLS];
+    uint4 d[LDS_COLS];
+#pragma unroll
+    for (int j = 0; j < LDS_COLS; ++j) col[j] = ln.lc[(j < (int)n ? j : 0) * ALIGN_BLOCK];
+#pragma unroll
+    for (int j = 0; j < LDS_COLS; ++j) d[j] = ix.cls_desc[col[j]];
+    base = d[0].y;
+#pragma unroll
+    for (int j = 0; j < LDS_COLS; ++j) {
+      if (j < (int)n) {
+        const uint32_t l = desc_len(d[j]);
+        if (l < bl) { bl = l; best = col[j]; }
+        all_mask &= desc_is_mask(d[j]);
+        acc &= mask_in_window(d[j], base);
+      }
+    }
+  } else {
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t c = get_col(ln, j);
+      const uint4 dj = ix.cls_desc[c];
+      if (j == 0) base = dj.y;
+      const uint32_t l = desc_len(dj);
+      if (l < bl) { bl = l; best = c; }
+      all_mask &= desc_is_mask(dj);
+      acc &= mask_in_window(dj, base);
+    }
   }
   best_col = best;
   best_len = bl;
-  const ClsDesc bd = load_desc(ix, best);
-  uint32_t count = 0;
+  mr.is_mask = all_mask;
+  mr.base = 0;
+  mr.mask = 0;
+  if (!all_mask) {
+    const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ln.lc, ln.ws, ln.ws_lanes, n, best, bl, out);
+    hash = r.hash;
+    return r.count;
+  }
+  const uint32_t count = (uint32_t)__popcll(acc);
+  if (acc) {
+    const uint32_t tz = (uint32_t)__ffsll((long long)acc) - 1u;
+    mr.base = base + tz;
+    mr.mask = acc >> tz;
+  }
   uint64_t h = class_hash_init();
-  if (bl <= CLS_INLINE_IDS) {
-    // small base class: survivors tracked in a bit mask, every other colour visited once
-    uint32_t alive = (1u << bl) - 1u;
-    for (uint32_t j = 0; j < ln.n_cols && alive; ++j) {
-      uint32_t c = get_col(ln, j);
-      if (c == best) continue;
-      const ClsDesc od = load_desc(ix, c);
-#pragma unroll
-      for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t)
-        if ((alive >> t) & 1u)
-          if (!class_contains(ix, od, desc_id(bd, t))) alive &= ~(1u << t);
-    }
-#pragma unroll
-    for (uint32_t t = 0; t < CLS_INLINE_IDS; ++t)
-      if ((alive >> t) & 1u) {
-        uint32_t id = desc_id(bd, t);
-        if (out) out[count] = id;
-        h = class_hash_step(h, id);
-        ++count;
-      }
-  } else {
-    const uint32_t *bids = ix.cls_ids + bd.a.y;
-    for (uint32_t t = 0; t < bl; ++t) {
-      uint32_t id = bids[t];
-      bool ok = true;
-      for (uint32_t j = 0; j < ln.n_cols; ++j) {
-        uint32_t c = get_col(ln, j);
-        if (c == best) continue;
-        if (!class_contains(ix, load_desc(ix, c), id)) { ok = false; break; }
-      }
-      if (ok) {
-        if (out) out[count] = id;
-        h = class_hash_step(h, id);
-        ++count;
-      }
-    }
+  uint32_t k = 0;
+  for (uint64_t m = acc; m; m &= m - 1) {
+    const uint32_t id = base + (uint32_t)__ffsll((long long)m) - 1u;
+    if (out) out[k] = id;
+    h = class_hash_step(h, id);
+    ++k;
   }
   hash = class_hash_final(h, count);
   return count;
@@ -532,7 +591,10 @@ __device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t 
 // ---------------------------------------------------------------------------------------------
 // k_align: walk + class + thresholds, one lane per read(-pair), persistent grid-stride blocks
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align_params p, CallBuffers cb,
+#ifndef NIMBLE_ALIGN_WAVES
+#define NIMBLE_ALIGN_WAVES 5
+#endif
+__global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p, CallBuffers cb,
                                                        int want_counters) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
   const uint32_t tid = threadIdx.x;
@@ -581,6 +643,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
       uint32_t reason = NIMBLE_R_NONE, score = 0, mm = 0, cls = CLS_NONE;
       uint32_t need = 0, best_col = 0, best_len = 0;
       uint64_t dhash = 0;
+      MaskRes mres;
+      mres.is_mask = false;
+      mres.base = 0;
+      mres.mask = 0;
       if (active) {
         uint32_t pre = cb.pre[m][r];
         if (pre != R_TODO) {
@@ -596,11 +662,15 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
             score = cov;
             mm = mis;
             uint32_t count;
+#ifdef NIMBLE_ABL_NO_INTERSECT
+            if (true) {
+#else
             if (ln.n_cols == 1) {
+#endif
               best_col = get_col(ln, 0);
-              best_len = count = ix.cls_desc[(size_t)best_col * 2].x;
+              best_len = count = desc_len(ix.cls_desc[best_col]);
             } else {
-              count = intersect_cols(ix, ln, best_col, best_len, dhash, nullptr);
+              count = intersect_cols(ix, ln, best_col, best_len, dhash, nullptr, mres);
             }
             double normalized = (double)cov / (double)L[m];
             if (p.discard_nonzero_mismatch && mis != 0) {
@@ -610,8 +680,32 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
               else if (mis > p.num_mismatches) reason = NIMBLE_R_ABOVE_MISMATCH_THRESHOLD;
               else {
                 reason = NIMBLE_R_SUCCESSFUL_MATCH;
-                if (count == best_len) cls = best_col;  // the intersection is the smallest colour itself
-                else { cls = CLS_PENDING; need = count; }
+                if (count == best_len) {
+                  cls = best_col;  // the intersection is the smallest colour itself
+                } else {
+                  // an intersection that is not one of the visited colours: find its canonical id in the
+                  // content-addressed class table (exact compare of the mask form); only a class never seen
+                  // before goes through the claim / verify kernels
+                  cls = CLS_PENDING;
+                  if (mres.is_mask) {
+                    const uint32_t tag = intern_tag(dhash);
+                    uint64_t pos = dhash & ix.intern_mask;
+                    for (;;) {
+                      const uint64_t slot = ix.intern[pos];
+                      if (slot == 0) break;
+                      const uint32_t id = (uint32_t)slot;
+                      if ((uint32_t)(slot >> 32) == tag && id != INTERN_PENDING && id < ix.cls_cap) {
+                        const uint4 d = ix.cls_desc[id];
+                        if (d.x == (count | CLS_MASK_FLAG) && d.y == mres.base && desc_mask(d) == mres.mask) {
+                          cls = id;
+                          break;
+                        }
+                      }
+                      pos = (pos + 1) & ix.intern_mask;
+                    }
+                  }
+                  if (cls == CLS_PENDING) need = count;
+                }
               }
             } else {
               reason = NIMBLE_R_SCORE_BELOW_THRESHOLD;
@@ -631,7 +725,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK) void k_align(DevIndex ix, nimble_align
         if (base + ofs + need <= (unsigned long long)cb.scratch_cap) {
           uint32_t bc, bl;
           uint64_t hh;
-          intersect_cols(ix, ln, bc, bl, hh, cb.scratch + base + ofs);
+          MaskRes m2;
+          intersect_cols(ix, ln, bc, bl, hh, cb.scratch + base + ofs, m2);
           cb.dyn_off[m][r] = (uint32_t)base + ofs;
           cb.dyn_len[m][r] = need;
           cb.dyn_hash[m][r] = dhash;
@@ -692,14 +787,11 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
         return;
       }
       const uint32_t *src = cb.scratch + cb.dyn_off[m][i];
-      uint32_t first[CLS_INLINE_IDS] = {0, 0, 0, 0, 0, 0};
-      for (uint32_t t = 0; t < len; ++t) {
-        uint32_t v = src[t];
-        ix.cls_ids[off + t] = v;
-        if (t < CLS_INLINE_IDS) first[t] = v;
-      }
-      ix.cls_desc[(size_t)id * 2] = make_uint4(len, off, first[0], first[1]);
-      ix.cls_desc[(size_t)id * 2 + 1] = make_uint4(first[2], first[3], first[4], first[5]);
+      for (uint32_t t = 0; t < len; ++t) ix.cls_ids[off + t] = src[t];
+      uint32_t desc[4];
+      make_class_desc(src, len, desc);
+      ix.cls_off[id] = off;
+      ix.cls_desc[id] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
       ix.intern[pos] = ((uint64_t)tag << 32) | id;
       cb.dyn_pos[m][i] = (uint32_t)pos;
       return;
@@ -720,11 +812,11 @@ __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
   const uint32_t id = (uint32_t)ix.intern[cb.dyn_pos[m][i]];
   const uint32_t len = cb.dyn_len[m][i];
   uint4 d0 = make_uint4(0, 0, 0, 0);
-  if (id < ix.cls_cap) d0 = ix.cls_desc[(size_t)id * 2];
-  bool same = id < ix.cls_cap && d0.x == len;
+  if (id < ix.cls_cap) d0 = ix.cls_desc[id];
+  bool same = id < ix.cls_cap && desc_len(d0) == len;
   if (same) {
     const uint32_t *a = cb.scratch + cb.dyn_off[m][i];
-    const uint32_t *b = ix.cls_ids + d0.y;
+    const uint32_t *b = ix.cls_ids + ix.cls_off[id];
     for (uint32_t t = 0; t < len; ++t)
       if (a[t] != b[t]) { same = false; break; }
   }

@@ -198,6 +198,42 @@ def test_ragged_and_edge_reads(synth_case):
         case.check(b, o, cfg=case.cfg.copy(num_mismatches=nm, score_percent=0.1, score_threshold=30))
 
 
+def test_wide_classes_general_intersection_path():
+    """Features far apart in the library share conserved segments: their k-mer classes span >= 64 rows, so
+    the intersection leaves the 64-bit-mask fast path (mixed with local classes at the segment borders)."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(k):
+        return acgt[rng.integers(0, 4, size=k)].tobytes().decode()
+    dom_all, dom_a, dom_b = rnd(120), rnd(90), rnd(90)
+    names, seqs = [], []
+    for i in range(90):
+        s = rnd(200) + dom_all + rnd(150)
+        if i % 3 == 0:
+            s += dom_a
+        if i % 5 == 0:
+            s += dom_b + rnd(60)
+        if i % 7 == 0:
+            s = s[:100] + s[:100] + s[100:]  # internal repeat: a k-mer twice in one row
+        names.append("D%03d" % i)
+        seqs.append(s + rnd(100))
+    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=30, max_hits_to_report=200))
+    reads = []
+    for _ in range(6000):
+        f = int(rng.integers(0, len(seqs)))
+        st = int(rng.integers(0, len(seqs[f]) - 150))
+        r = np.frombuffer(seqs[f][st:st + 150].encode(), dtype=np.uint8).copy()
+        if rng.random() < 0.4:
+            r[int(rng.integers(0, 150))] = ord("ACGT"[int(rng.integers(0, 4))])
+        reads.append(r.tobytes())
+    b, o = ora.pack_reads(reads)
+    for nm in (0, 2):
+        case.check(b, o, cfg=case.cfg.copy(num_mismatches=nm))
+    st = case.dindex.stats()
+    assert st["dynamic_classes"] > 0  # intersections that are not k-mer colours were interned on the device
+
+
 def test_empty_call(synth_case):
     case, _ = synth_case
     b, o = ora.pack_reads([])
