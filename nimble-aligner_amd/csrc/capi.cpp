@@ -378,8 +378,8 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.ht = ix->b_ht.as<uint4>();
   d.ht_mask = fi.ht_slots - 1;
   d.ht_log2 = fi.ht_log2;
-  d.bitmap = ix->b_bitmap.as<uint32_t>();
-  d.bm_log2 = fi.bm_log2;
+  d.bitmap = ix->b_bitmap.as<uint4>();
+  d.bm_lines_log2 = fi.bm_lines_log2;
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();

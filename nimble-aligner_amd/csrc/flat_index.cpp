@@ -151,17 +151,18 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     tail[nd] = last;
     uint64_t len = (uint64_t)o + KMER - 1;
     if (bases + len >= (1ULL << 32)) throw std::runtime_error("index build: unitig buffer exceeds 2^32 bases");
-    out.node_rec[nd * 16 + 0] = (uint32_t)len;
+    if (len >= (1u << 24)) throw std::runtime_error("index build: unitig longer than 2^24 bases");
+    const uint32_t e = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
+    out.node_rec[nd * 16 + 0] = (uint32_t)len | (e << 24);
     out.node_rec[nd * 16 + 1] = colour[heads[nd]];
-    out.node_rec[nd * 16 + 2] = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
-    out.node_rec[nd * 16 + 3] = (uint32_t)bases;
+    out.node_rec[nd * 16 + 2] = (uint32_t)bases;
     bases += len;
   }
   out.unitig_bases = bases;
   out.unitig.assign((bases + 31) / 32 + 4, 0);  // +4 words so a 3-word window never reads past the end
   auto put_base = [&](uint64_t pos, uint64_t b) { out.unitig[pos >> 5] |= b << (62 - 2 * (pos & 31)); };
   for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint64_t pos = out.node_rec[nd * 16 + 3];
+    uint64_t pos = out.node_rec[nd * 16 + 2];
     uint64_t inl[4] = {0, 0, 0, 0};
     uint32_t k = 0;
     auto put = [&](uint64_t b) {
@@ -172,20 +173,20 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     uint64_t first = kmers[heads[nd]];
     for (uint32_t b = 0; b < KMER; ++b) put((first >> (2 * (KMER - 1 - b))) & 3);
     for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put(kmers[c] & 3);
-    for (int w = 0; w < 4; ++w) {
-      out.node_rec[nd * 16 + 8 + 2 * w] = (uint32_t)inl[w];
-      out.node_rec[nd * 16 + 9 + 2 * w] = (uint32_t)(inl[w] >> 32);
+    for (int w = 0; w < 2; ++w) {
+      out.node_rec[nd * 16 + 12 + 2 * w] = (uint32_t)inl[w];
+      out.node_rec[nd * 16 + 13 + 2 * w] = (uint32_t)(inl[w] >> 32);
     }
   }
   // 5. edges
   for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint32_t e = out.node_rec[nd * 16 + 2];
+    uint32_t e = out.node_rec[nd * 16 + 0] >> 24;
     uint64_t firstk = kmers[heads[nd]], lastk = kmers[tail[nd]];
     for (uint32_t b = 0; b < 4; ++b) {
       if ((e >> 4) & (1u << b)) {
         size_t j = find(((lastk << 2) | b) & KMER_MASK);
         if (kmer_off[j] != 0) throw std::runtime_error("index build: right edge does not land on a unitig start");
-        out.node_rec[nd * 16 + 4 + b] = kmer_node[j];
+        out.node_rec[nd * 16 + 8 + b] = kmer_node[j];
       }
       if (e & (1u << b)) {
         size_t j = find(((uint64_t)b << (2 * (KMER - 1))) | (firstk >> 2));
@@ -209,17 +210,27 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     out.ht[2 * h] = kmers[i];
     out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
   }
-  out.bm_log2 = log2_slots + 2;
-  out.bitmap.assign((size_t)1 << (out.bm_log2 - 5), 0);
+  // presence filter: 7 bits per k-mer, sized for <= 8 % density (the 24 shared bits allow up to 2^24 lines)
+  out.bm_lines_log2 = 8;
+  while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND > 0.08 * 128.0 * (double)(1ull << out.bm_lines_log2))
+    ++out.bm_lines_log2;
+  out.bitmap.assign((size_t)4 << out.bm_lines_log2, 0);
   for (size_t i = 0; i < n; ++i) {
-    uint64_t b = kmer_slot(kmers[i], out.bm_log2);
-    out.bitmap[b >> 5] |= 1u << (b & 31);
+    const uint32_t bit = round_bit(kmers[i]);
+    for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
+      const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
+      out.bitmap[line * 4 + (bit >> 5)] |= 1u << (bit & 31);
+    }
   }
   // 7. class descriptors
   out.cls_desc.assign(out.n_colours * 4, 0);
   for (size_t c = 0; c < out.n_colours; ++c) {
     uint32_t o = out.col_off[c], l = out.col_off[c + 1] - o;
     make_class_desc(out.col_ids.data() + o, l, &out.cls_desc[c * 4]);
+  }
+  for (size_t nd = 0; nd < n_nodes; ++nd) {
+    const uint32_t c = out.node_rec[nd * 16 + 1];
+    for (int k = 0; k < 4; ++k) out.node_rec[nd * 16 + 3 + k] = out.cls_desc[(size_t)c * 4 + k];
   }
 }
 

@@ -16,7 +16,7 @@ namespace nimble {
 constexpr uint32_t KMER = 30;
 constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
-constexpr uint32_t NODE_INLINE_BASES = 128;
+constexpr uint32_t NODE_INLINE_BASES = 64;
 constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
 constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;  // set in the descriptor's len word when the mask form is valid
 
@@ -41,6 +41,26 @@ NIMBLE_HD uint64_t kmer_slot(uint64_t km, uint32_t log2_slots) {
   const uint32_t f = (uint32_t)km ^ (uint32_t)(km >> 29);
   return (uint64_t)((f * 0x9E3779B1u) >> (32u - log2_slots));
 }
+// Round-anchored presence filter.  A seed scan looks at SCAN_ROUND = 7 positions p, p+3, .., p+18 per
+// round; the 7 k-mers of a round share the 12 bases [p+18, p+30).  Those 24 bits select a 128-bit filter
+// line, the k-mer itself selects the bit inside the line, so ONE 16-byte load answers a whole round.
+// At build time every indexed k-mer sets its bit in the 7 lines it can be asked under (slot j of a round
+// <-> shared bases at offset 3(6-j) of the k-mer).
+constexpr uint32_t SCAN_ROUND = 7;
+constexpr uint32_t SCAN_SHARED = 30 - 3 * (SCAN_ROUND - 1);  // 12 bases
+NIMBLE_HD uint64_t round_line(uint64_t shared, uint32_t lines_log2) {
+  return (uint64_t)(((uint32_t)shared * 0x85EBCA6Bu) >> (32u - lines_log2));
+}
+NIMBLE_HD uint32_t round_bit(uint64_t km) {  // 0..127
+  const uint32_t f = (uint32_t)km ^ (uint32_t)(km >> 31);
+  return (f * 0xC2B2AE35u) >> 25;
+}
+// the shared bases of k-mer km when it sits in slot j of a round
+NIMBLE_HD uint64_t round_shared_of_kmer(uint64_t km, uint32_t j) {
+  const uint32_t start = 3u * (SCAN_ROUND - 1u - j);  // offset of the shared bases inside the k-mer
+  return (km >> (2u * (30u - start - SCAN_SHARED))) & ((1ULL << (2u * SCAN_SHARED)) - 1ULL);
+}
+
 // content hash of an equivalence class (ascending ids); streaming form
 NIMBLE_HD uint64_t class_hash_init() { return 0x9E3779B97F4A7C15ULL; }
 NIMBLE_HD uint64_t class_hash_step(uint64_t h, uint32_t id) {
@@ -83,14 +103,22 @@ struct FlatIndex {
   std::vector<uint64_t> ht;  // 2 x u64 per slot
   uint64_t ht_slots = 0;     // power of two
   uint32_t ht_log2 = 0;
-  // presence bitmap over the same hash, 4 bits per dictionary slot (one bit per k-mer hash value at
-  // ht_log2 + 2 bits): small enough to stay in L2, it answers most absent-k-mer probes
-  std::vector<uint32_t> bitmap;
-  uint32_t bm_log2 = 0;
-  // node record, one 64-byte line per unitig so that a hop costs one dependent memory level:
-  //   u32[0..3]  = {len (bases), colour, exts (lext | rext<<4), seq_start (base offset into unitig)}
-  //   u32[4..7]  = right-edge target node per base
-  //   u32[8..15] = the first 128 bases, 4 x u64 (low word first), base i at word i>>5, bits 62-2*(i&31)
+  // round-anchored presence filter (see round_line / round_bit): lines of 128 bits
+  std::vector<uint32_t> bitmap;      // 4 x u32 per line
+  uint32_t bm_lines_log2 = 0;
+  // node record, one 64-byte line per unitig so that a hop costs one dependent memory level and the
+  // class intersection needs no load at all:
+  //   u32[0]      = len (bases, low 24 bits) | exts (lext | rext<<4) << 24
+  //   u32[1]      = colour (class id)
+  //   u32[2]      = seq_start (base offset into unitig)
+  //   u32[3]      = class descriptor word 0: class length | CLS_MASK_FLAG
+  //   u32[4]      = class base row
+  //   u32[5..6]   = class mask (lo, hi)
+  //   u32[7]      = 0
+  //   u32[8..11]  = right-edge target node per base
+  //   u32[12..15] = bases 0..63 (2 x u64, low word first), base i at word i>>5, bits 62-2*(i&31)
+  // plus a second record line used only by unitigs longer than 64 bases is avoided: bases 64.. come from
+  // the packed unitig buffer.
   std::vector<uint32_t> node_rec;    // 16 x u32 per node
   std::vector<uint32_t> node_ledge;  // 4 x u32 per node (left extension only)
   std::vector<uint64_t> unitig;      // 2-bit packed, base i at word i>>5, bits 62-2*(i&31)

@@ -19,8 +19,8 @@ struct DevIndex {
   const uint4 *ht;          // {key lo, key hi, offset, node}
   uint64_t ht_mask;
   uint32_t ht_log2;
-  const uint32_t *bitmap;   // presence filter: bit kmer_slot(km, bm_log2)
-  uint32_t bm_log2;
+  const uint4 *bitmap;      // round-anchored presence filter, one 128-bit line per uint4 (flat_index.h)
+  uint32_t bm_lines_log2;
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;

@@ -143,7 +143,6 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
 // ---------------------------------------------------------------------------------------------
 // k_align helpers
 // ---------------------------------------------------------------------------------------------
-constexpr int PROBE_BATCH = 8;  // seed positions screened per round after the first miss
 
 struct Lane {
   const uint64_t *rd;  // LDS column holding the packed key (stride ALIGN_BLOCK words)
@@ -151,28 +150,36 @@ struct Lane {
   uint32_t *ws;        // global spill column (stride ws_lanes)
   uint32_t ws_lanes, ws_rows;
   uint32_t n_cols, last_col, walk_nodes;
+  // running intersection of the visited colours (mask form): window base, surviving rows, smallest class
+  uint64_t acc;
+  uint32_t fbase, min_len, min_col;
+  bool all_mask;
   uint32_t probes, nodes;
   uint64_t entries;
-  const uint4 *cls_desc;
   int want_counters;
   uint32_t overflow;
 };
 
-// one unitig: header, right edges and the first 128 bases, all from one 64-byte line
+// one unitig, all from one 64-byte line: header, the descriptor of its colour class, right edges and the
+// first 64 bases (layout: flat_index.h)
 struct NodeRec {
-  uint4 h;   // {len, colour, exts, seq_start}
+  uint4 q0;  // {len | exts << 24, colour, seq_start, class len | flag}
+  uint4 q1;  // {class base, mask lo, mask hi, 0}
   uint4 re;  // right-edge targets
-  uint4 s0, s1;
+  uint4 sq;  // bases 0..63
 };
 __device__ __forceinline__ NodeRec load_node(const DevIndex &ix, uint32_t node) {
   const uint4 *p = ix.node_rec + (size_t)node * 4;
   NodeRec r;
-  r.h = p[0];
-  r.re = p[1];
-  r.s0 = p[2];
-  r.s1 = p[3];
+  r.q0 = p[0];
+  r.q1 = p[1];
+  r.re = p[2];
+  r.sq = p[3];
   return r;
 }
+__device__ __forceinline__ uint32_t nr_len(const NodeRec &r) { return r.q0.x & 0xFFFFFFu; }
+__device__ __forceinline__ uint32_t nr_exts(const NodeRec &r) { return r.q0.x >> 24; }
+__device__ __forceinline__ uint4 nr_desc(const NodeRec &r) { return make_uint4(r.q0.w, r.q1.x, r.q1.y, r.q1.z); }
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
 // nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
@@ -192,19 +199,18 @@ __device__ __forceinline__ uint64_t g_bits(const uint64_t *__restrict__ u, uint6
   uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
   return x >> (64u - 2u * nb);
 }
-// nb bases of a unitig at node-relative position pos: from the record while inside its 128 inline bases
+// nb bases of a unitig at node-relative position pos: from the record while inside its 64 inline bases
 __device__ __forceinline__ uint64_t node_bits(const NodeRec &r, const uint64_t *__restrict__ unitig, uint32_t pos,
                                               uint32_t nb) {
   if (pos + nb <= NODE_INLINE_BASES) {
-    const uint64_t w0 = u64of(r.s0.x, r.s0.y), w1 = u64of(r.s0.z, r.s0.w);
-    const uint64_t w2 = u64of(r.s1.x, r.s1.y), w3 = u64of(r.s1.z, r.s1.w);
-    const uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
-    const uint64_t hi = w == 0 ? w0 : (w == 1 ? w1 : (w == 2 ? w2 : w3));
-    const uint64_t lo = w == 0 ? w1 : (w == 1 ? w2 : (w == 2 ? w3 : 0ULL));
+    const uint64_t w0 = u64of(r.sq.x, r.sq.y), w1 = u64of(r.sq.z, r.sq.w);
+    const uint32_t s = (pos & 31u) * 2u;
+    const uint64_t hi = pos < 32u ? w0 : w1;
+    const uint64_t lo = pos < 32u ? w1 : 0ULL;
     const uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
     return x >> (64u - 2u * nb);
   }
-  return g_bits(unitig, (uint64_t)r.h.w + pos, nb);
+  return g_bits(unitig, (uint64_t)r.q0.z + pos, nb);
 }
 __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t b) {
   return b == 0 ? v.x : (b == 1 ? v.y : (b == 2 ? v.z : v.w));
@@ -242,40 +248,36 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
     kmer_pos += 3;
   }
   while (kmer_pos <= last_kmer_pos) {
-    // PROBE_BATCH positions screened through the L2-resident presence bitmap, all loads in flight at once
-    uint32_t word[PROBE_BATCH], bit[PROBE_BATCH];
+    // one round: SCAN_ROUND positions at stride 3, answered by ONE 16-byte line of the presence filter,
+    // selected by the 12 bases all 7 k-mers share
+    uint32_t maybe = 0;
     {
-      // k-mers at stride 3 by rolling: drop 3 bases, append 3 (one LDS window fetch per 8 positions
-      // instead of 8); positions past the end reuse the last valid k-mer and are ignored below
-      const uint32_t span = KMER + 3u * (PROBE_BATCH - 1);  // bases covered by the round: 51
-      const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;  // bases of the mate from kmer_pos on
+      const uint32_t span = KMER + 3u * (SCAN_ROUND - 1);            // 48 bases
+      const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;      // bases of the mate from kmer_pos on
       uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
-      // the 21 bases behind the first k-mer, left-aligned in `tail` (zero-filled past the mate's end)
       const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
-      uint64_t tail = extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
+      const uint64_t tail =
+          extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
+      const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
 #pragma unroll
-      for (int i = 0; i < PROBE_BATCH; ++i) {
-        const uint64_t b = kmer_slot(km, ix.bm_log2);
-        bit[i] = (uint32_t)b & 31u;
-        word[i] = ix.bitmap[b >> 5];
-        // next k-mer: shift in the next 3 bases of the tail
-        if (i + 1 < PROBE_BATCH) {
+      for (int i = 0; i < (int)SCAN_ROUND; ++i) {
+        const uint32_t b = round_bit(km);
+        const uint32_t w = (b >> 5) == 0 ? line.x : ((b >> 5) == 1 ? line.y : ((b >> 5) == 2 ? line.z : line.w));
+        maybe |= ((w >> (b & 31u)) & 1u) << i;
+        if (i + 1 < (int)SCAN_ROUND) {
           const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
           km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
         }
       }
     }
-    uint32_t maybe = 0;
-#pragma unroll
-    for (int i = 0; i < PROBE_BATCH; ++i) maybe |= ((word[i] >> bit[i]) & 1u) << i;
     const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
     bool found = false;
     uint32_t fpos = 0;
 #pragma unroll
-    for (int i = 0; i < PROBE_BATCH; ++i) {
+    for (int i = 0; i < (int)SCAN_ROUND; ++i) {
       if (!found && 3u * i <= valid) {
         ln.probes++;
-        if ((maybe >> i) & 1u) {  // rare after a first miss: bitmap false positive or a real seed
+        if ((maybe >> i) & 1u) {  // rare after a first miss: filter false positive or a real seed
           const uint32_t p = kmer_pos + 3u * i;
           const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
           const uint64_t h = kmer_slot(km, ix.ht_log2);
@@ -300,16 +302,42 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
       kmer_pos = fpos;
       return true;
     }
-    kmer_pos += 3u * PROBE_BATCH;
+    kmer_pos += 3u * SCAN_ROUND;
   }
   return false;
 }
 
-__device__ __forceinline__ void push_col(Lane &ln, uint32_t colour) {
+__device__ __forceinline__ uint32_t desc_len(const uint4 &d) { return d.x & ~CLS_MASK_FLAG; }
+__device__ __forceinline__ bool desc_is_mask(const uint4 &d) { return (d.x & CLS_MASK_FLAG) != 0; }
+__device__ __forceinline__ uint64_t desc_mask(const uint4 &d) { return u64of(d.z, d.w); }
+
+// mask of class d expressed in the window starting at row `base`
+__device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base) {
+  const uint64_t m = desc_mask(d);
+  const int32_t delta = (int32_t)(d.y - base);
+  if (delta >= 0) return delta < 64 ? (m << delta) : 0ULL;
+  return -delta < 64 ? (m >> (-delta)) : 0ULL;
+}
+
+// a visited node: counters, running intersection, and the colour list kept for the general (non-mask) path
+__device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 &desc) {
   ln.nodes++;
   ln.walk_nodes++;
-  if (ln.want_counters) ln.entries += ln.cls_desc[colour].x & ~CLS_MASK_FLAG;
+  if (ln.want_counters) ln.entries += desc_len(desc);
   if (ln.n_cols && colour == ln.last_col) return;  // intersection is idempotent
+  const uint32_t l = desc_len(desc);
+  if (ln.n_cols == 0) {
+    ln.fbase = desc.y;
+    ln.acc = ~0ULL;
+    ln.all_mask = true;
+    ln.min_len = l;
+    ln.min_col = colour;
+  } else if (l < ln.min_len) {
+    ln.min_len = l;
+    ln.min_col = colour;
+  }
+  ln.all_mask = ln.all_mask && desc_is_mask(desc);
+  ln.acc &= mask_in_window(desc, ln.fbase);
   uint32_t j = ln.n_cols;
   ln.last_col = colour;
   if (j < LDS_COLS) {
@@ -321,9 +349,6 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour) {
     return;
   }
   ln.n_cols = j + 1;
-}
-__device__ __forceinline__ uint32_t get_col(const Lane &ln, uint32_t j) {
-  return j < LDS_COLS ? ln.lc[j * ALIGN_BLOCK] : ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes];
 }
 
 // compare n bases forward: key[rpos + i] vs unitig[upos + i] (upos node-relative).  Returns the bases
@@ -408,30 +433,27 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
       if (last_pos + 1 - matched == 0 || prem) break;
       last_pos -= matched;
       uint32_t nbase = lds_base(ln.rd, base0 + last_pos);
-      if (nr.h.z & (1u << nbase)) {
+      if (nr_exts(nr) & (1u << nbase)) {
         uint4 le = ix.node_ledge[pnode];
         pnode = sel4(le, nbase);
-        uint4 h2 = ix.node_rec[(size_t)pnode * 4];
-        poff = h2.x - KMER;
-        push_col(ln, h2.y);
+        const uint4 h0 = ix.node_rec[(size_t)pnode * 4], h1 = ix.node_rec[(size_t)pnode * 4 + 1];
+        poff = (h0.x & 0xFFFFFFu) - KMER;
+        push_col(ln, h0.y, make_uint4(h0.w, h1.x, h1.y, h1.z));
       } else {
         break;
       }
     }
   }
   if (kmer_pos <= last_kmer_pos) {  // forward search (a seed was found)
-#ifdef NIMBLE_ABL_NO_WALK
-    push_col(ln, node);
-    if (false)
-#endif
+
     for (;;) {
       NodeRec nr = load_node(ix, node);
       kmer_pos += KMER;
       cov += KMER;
-      push_col(ln, nr.h.y);
+      push_col(ln, nr.q0.y, nr_desc(nr));
       uint32_t remaining = L - kmer_pos;
       uint32_t ref_off = koff + KMER;
-      uint32_t informative = nr.h.x - ref_off;
+      uint32_t informative = nr_len(nr) - ref_off;
       uint32_t n = remaining < informative ? remaining : informative;
       bool prem = false;
       uint32_t matched = 0;
@@ -440,7 +462,7 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
       kmer_pos += matched;
       if (kmer_pos >= L) break;
       uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
-      if (!prem && ((nr.h.z >> 4) & (1u << nbase))) {
+      if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
         node = sel4(nr.re, nbase);
         koff = 0;
         kmer_pos -= KMER - 1;
@@ -458,17 +480,6 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
 }
 
 // class table access ------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t desc_len(const uint4 &d) { return d.x & ~CLS_MASK_FLAG; }
-__device__ __forceinline__ bool desc_is_mask(const uint4 &d) { return (d.x & CLS_MASK_FLAG) != 0; }
-__device__ __forceinline__ uint64_t desc_mask(const uint4 &d) { return u64of(d.z, d.w); }
-
-// mask of class d expressed in the window starting at row `base`
-__device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base) {
-  const uint64_t m = desc_mask(d);
-  const int32_t delta = (int32_t)(d.y - base);
-  if (delta >= 0) return delta < 64 ? (m << delta) : 0ULL;
-  return -delta < 64 ? (m >> (-delta)) : 0ULL;
-}
 
 // general form of nodes_to_eq_class (some visited class spans 64 rows or more): smallest class first,
 // membership test of each of its rows in every other visited class.  Everything is passed and returned by
@@ -517,69 +528,35 @@ __device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint
   return r;
 }
 
-// nodes_to_eq_class: intersection of the visited colours.  Returns the class length, the smallest visited
-// class (best_col / best_len: when the result has that length it *is* that class), the content hash, and
-// writes the ids to `out` when non-null.  Local classes fold as 64-bit masks: one 16-byte load per colour.
+// nodes_to_eq_class.  The mask-form intersection was folded during the walk (push_col); this turns it into
+// the class length, the content hash and, when `out` is given, the ascending row ids.  best_col / best_len
+// = the smallest visited class: a result of that length *is* that class.
 struct MaskRes {  // the result as base + mask (valid when is_mask), normalised so that bit 0 is set
   bool is_mask;
   uint32_t base;
   uint64_t mask;
 };
-__device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t &best_col, uint32_t &best_len,
-                                   uint64_t &hash, uint32_t *out, MaskRes &mr) {
-  const uint32_t n = ln.n_cols;
-  uint32_t best = 0, bl = 0xFFFFFFFFu, base = 0;
-  uint64_t acc = ~0ULL;
-  bool all_mask = true;
-  if (n <= LDS_COLS) {
-    // all descriptor loads in flight together
-    uint32_t col[LDS_COLS];
-    uint4 d[LDS_COLS];
-#pragma unroll
-    for (int j = 0; j < LDS_COLS; ++j) col[j] = ln.lc[(j < (int)n ? j : 0) * ALIGN_BLOCK];
-#pragma unroll
-    for (int j = 0; j < LDS_COLS; ++j) d[j] = ix.cls_desc[col[j]];
-    base = d[0].y;
-#pragma unroll
-    for (int j = 0; j < LDS_COLS; ++j) {
-      if (j < (int)n) {
-        const uint32_t l = desc_len(d[j]);
-        if (l < bl) { bl = l; best = col[j]; }
-        all_mask &= desc_is_mask(d[j]);
-        acc &= mask_in_window(d[j], base);
-      }
-    }
-  } else {
-    for (uint32_t j = 0; j < n; ++j) {
-      const uint32_t c = get_col(ln, j);
-      const uint4 dj = ix.cls_desc[c];
-      if (j == 0) base = dj.y;
-      const uint32_t l = desc_len(dj);
-      if (l < bl) { bl = l; best = c; }
-      all_mask &= desc_is_mask(dj);
-      acc &= mask_in_window(dj, base);
-    }
-  }
-  best_col = best;
-  best_len = bl;
-  mr.is_mask = all_mask;
+__device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &hash, uint32_t *out, MaskRes &mr) {
+  mr.is_mask = ln.all_mask;
   mr.base = 0;
   mr.mask = 0;
-  if (!all_mask) {
-    const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ln.lc, ln.ws, ln.ws_lanes, n, best, bl, out);
+  if (!ln.all_mask) {
+    const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ln.lc, ln.ws, ln.ws_lanes, ln.n_cols,
+                                     ln.min_col, ln.min_len, out);
     hash = r.hash;
     return r.count;
   }
+  const uint64_t acc = ln.acc;
   const uint32_t count = (uint32_t)__popcll(acc);
   if (acc) {
     const uint32_t tz = (uint32_t)__ffsll((long long)acc) - 1u;
-    mr.base = base + tz;
+    mr.base = ln.fbase + tz;
     mr.mask = acc >> tz;
   }
   uint64_t h = class_hash_init();
   uint32_t k = 0;
   for (uint64_t m = acc; m; m &= m - 1) {
-    const uint32_t id = base + (uint32_t)__ffsll((long long)m) - 1u;
+    const uint32_t id = ln.fbase + (uint32_t)__ffsll((long long)m) - 1u;
     if (out) out[k] = id;
     h = class_hash_step(h, id);
     ++k;
@@ -592,7 +569,7 @@ __device__ uint32_t intersect_cols(const DevIndex &ix, const Lane &ln, uint32_t 
 // k_align: walk + class + thresholds, one lane per read(-pair), persistent grid-stride blocks
 // ---------------------------------------------------------------------------------------------
 #ifndef NIMBLE_ALIGN_WAVES
-#define NIMBLE_ALIGN_WAVES 5
+#define NIMBLE_ALIGN_WAVES 8
 #endif
 __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p, CallBuffers cb,
                                                        int want_counters) {
@@ -606,12 +583,14 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   ln.ws_lanes = cb.ws_lanes;
   ln.ws_rows = cb.ws_rows;
   ln.ws = cb.ws_cols + ((uint64_t)blockIdx.x * ALIGN_BLOCK + tid);
-  ln.cls_desc = ix.cls_desc;
   ln.want_counters = want_counters;
   ln.probes = ln.nodes = 0;
   ln.entries = 0;
   ln.overflow = 0;
   ln.n_cols = ln.last_col = ln.walk_nodes = 0;
+  ln.acc = 0;
+  ln.fbase = ln.min_len = ln.min_col = 0;
+  ln.all_mask = true;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
   const int nm = cb.paired ? 2 : 1;
@@ -662,16 +641,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
             score = cov;
             mm = mis;
             uint32_t count;
-#ifdef NIMBLE_ABL_NO_INTERSECT
-            if (true) {
-#else
-            if (ln.n_cols == 1) {
-#endif
-              best_col = get_col(ln, 0);
-              best_len = count = desc_len(ix.cls_desc[best_col]);
-            } else {
-              count = intersect_cols(ix, ln, best_col, best_len, dhash, nullptr, mres);
-            }
+            best_col = ln.min_col;
+            best_len = ln.min_len;
+            if (ln.n_cols == 1) count = best_len;
+            else count = finish_class(ix, ln, dhash, nullptr, mres);
             double normalized = (double)cov / (double)L[m];
             if (p.discard_nonzero_mismatch && mis != 0) {
               reason = NIMBLE_R_DISCARDED_NONZERO_MISMATCH;
@@ -723,10 +696,9 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
       }
       if (need) {
         if (base + ofs + need <= (unsigned long long)cb.scratch_cap) {
-          uint32_t bc, bl;
           uint64_t hh;
           MaskRes m2;
-          intersect_cols(ix, ln, bc, bl, hh, cb.scratch + base + ofs, m2);
+          finish_class(ix, ln, hh, cb.scratch + base + ofs, m2);
           cb.dyn_off[m][r] = (uint32_t)base + ofs;
           cb.dyn_len[m][r] = need;
           cb.dyn_hash[m][r] = dhash;
