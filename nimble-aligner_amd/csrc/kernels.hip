@@ -95,33 +95,73 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
   }
   const uint32_t total = L[0] + L[1];
   uint64_t acc = 0, h = 0x8F1BBCDCCA62C1D6ULL ^ (uint64_t)total;
-  uint32_t nb = 0, w = 0;
-  for (int m = 0; m < nm; ++m) {
-    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
-    const uint8_t *q = p[m];
-    for (uint32_t i = 0; i < L[m]; ++i) {
-      uint32_t c = encode_base(q[i]);
-      cA += (c == 0);
-      cC += (c == 1);
-      cG += (c == 2);
-      cT += (c == 3);
-      acc = (acc << 2) | c;
-      if (++nb == 32) {
-        cb.keys[(uint64_t)w * n + r] = acc;
-        h = (h ^ acc) * 0xff51afd7ed558ccdULL;
-        h ^= h >> 32;
-        ++w;
-        nb = 0;
-        acc = 0;
-      }
+  uint32_t nb = 0, w = 0;            // bases pending in acc (< 32), words emitted
+  uint32_t nT = 0, nG = 0, nC = 0;   // running base counts over everything packed so far
+  uint32_t pT = 0, pG = 0, pC = 0;   // the same at the end of the previous mate
+  auto count_word = [&](uint64_t word) {
+    const uint64_t hi = (word >> 1) & 0x5555555555555555ULL, lo = word & 0x5555555555555555ULL;
+    nT += (uint32_t)__popcll(hi & lo);
+    nG += (uint32_t)__popcll(hi & ~lo);
+    nC += (uint32_t)__popcll(~hi & lo);
+  };
+  auto emit = [&](uint64_t word) {
+    cb.keys[(uint64_t)w * n + r] = word;
+    h = (h ^ word) * 0xff51afd7ed558ccdULL;
+    h ^= h >> 32;
+    ++w;
+    count_word(word);
+  };
+  // append k (1..4) bases given as 2k right-aligned bits
+  auto append = [&](uint32_t bits, uint32_t k) {
+    if (nb + k < 32u) {
+      acc = (acc << (2u * k)) | bits;
+      nb += k;
+    } else {
+      const uint32_t first = 32u - nb, rest = k - first;  // first >= 1
+      emit((acc << (2u * first)) | (bits >> (2u * rest)));
+      acc = bits & ((1u << (2u * rest)) - 1u);
+      nb = rest;
     }
-    cb.len[m][r] = L[m];
+  };
+  for (int m = 0; m < nm; ++m) {
+    // 4 bases per step: aligned LDS dwords funnel-shifted to the read's byte alignment, SWAR conversion
+    const uint32_t a = (uint32_t)(p[m] - lds);
+    const uint32_t mis = a & 3u;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(lds) + (a >> 2);
+    const uint32_t len = L[m];
+    uint32_t prev = q[0];
+    uint32_t i = 0;
+    for (uint32_t done = 0; done < len; done += 4, ++i) {
+      const uint32_t next = q[i + 1];
+      const uint32_t raw = __builtin_amdgcn_alignbyte(next, prev, mis);  // bytes done .. done+3 of the read
+      prev = next;
+      const uint32_t x = raw | 0x20202020u;                 // lower-case
+      uint32_t code = (x >> 1) & 0x03030303u;               // a->0 c->1 g->3 t->2
+      code ^= (code >> 1) & 0x01010101u;                    // a->0 c->1 g->2 t->3
+      const uint32_t letter = __builtin_amdgcn_perm(0u, 0x74676361u, code);  // code -> 'a','c','g','t'
+      const uint32_t d = letter ^ x;                        // zero byte <=> a valid base
+      const uint32_t zb = ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);  // 0x80 where valid
+      code &= (zb >> 7) * 0xFFu;                            // anything else encodes as 'A' (0)
+      const uint32_t packed = (code * 0x40100401u) >> 24;   // 4 codes -> 8 bits, first base highest
+      const uint32_t k = len - done < 4u ? len - done : 4u;
+      append(packed >> (2u * (4u - k)), k);
+    }
+    cb.len[m][r] = len;
+    // base counts of this mate: totals so far (emitted words + the pending bases) minus the previous mate's
+    const uint64_t phi = (acc >> 1) & 0x5555555555555555ULL, plo = acc & 0x5555555555555555ULL;
+    const uint32_t tT = nT + (uint32_t)__popcll(phi & plo), tG = nG + (uint32_t)__popcll(phi & ~plo);
+    const uint32_t tC = nC + (uint32_t)__popcll(~phi & plo & ((nb ? (1ULL << (2u * nb)) : 1ULL) - 1ULL));
+    const uint32_t cT = tT - pT, cG = tG - pG, cC = tC - pC;
+    const uint32_t cA = len - cT - cG - cC;
+    pT = tT;
+    pG = tG;
+    pC = tC;
     uint8_t verdict = (uint8_t)R_TODO;
-    if (L[m] < min_len) {
+    if (len < min_len) {
       verdict = NIMBLE_R_SHORT_READ;
     } else {
       // shannon_entropy: sum f*log2(f) over A, T, C, G in that order, terms from the host-built table
-      const double *row = plog + ((uint64_t)L[m] * (L[m] + 1)) / 2;
+      const double *row = plog + ((uint64_t)len * (len + 1)) / 2;
       double e = 0.0;
       if (cA) e += row[cA];
       if (cT) e += row[cT];
@@ -132,9 +172,10 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     cb.pre[m][r] = verdict;
   }
   if (nb) {
-    acc <<= (64 - 2 * nb);
-    cb.keys[(uint64_t)w * n + r] = acc;
-    h = (h ^ acc) * 0xff51afd7ed558ccdULL;
+    // the last word is left-aligned; its padding is zero = 'A' codes, excluded from the counts above
+    const uint64_t word = acc << (64u - 2u * nb);
+    cb.keys[(uint64_t)w * n + r] = word;
+    h = (h ^ word) * 0xff51afd7ed558ccdULL;
     h ^= h >> 32;
   }
   cb.key_hash[r] = mix64(h);
