@@ -103,6 +103,9 @@ struct nimble_ctx {
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
   DevBuf b_plog;
   uint32_t plog_max_len = 0;
+  DevBuf b_min_cov;
+  double min_cov_percent = -1.0;
+  uint32_t min_cov_len = 0;
   DevBuf b_out_c1, b_out_c2, b_out_cnt;
   uint64_t scratch_cap = 0;
   uint64_t hist_slots = 0;
@@ -125,7 +128,7 @@ struct nimble_ctx {
                       &b_score[0], &b_score[1], &b_mism[0], &b_mism[1], &b_cls[0], &b_cls[1], &b_dyn_off[0],
                       &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
-                      &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_out_c1, &b_out_c2,
+                      &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
                       &b_out_cnt})
       b->release();
     if (have_events)
@@ -162,6 +165,31 @@ int ensure_plog(nimble_ctx *c, uint32_t max_len) {
   int rc = upload(c->b_plog, t, &c->bytes);
   if (rc) return rc;
   c->plog_max_len = m;
+  return NIMBLE_OK;
+}
+
+// min_cov[L] = smallest integer score s with (double)s / (double)L >= score_percent, evaluated with the
+// host's IEEE division -- the device then decides `normalized_score >= score_percent` (filter/align.rs:16)
+// with one integer compare, bit-exact
+int ensure_min_cov(nimble_ctx *c, double percent, uint32_t max_len) {
+  if (c->b_min_cov.p && c->min_cov_percent == percent && c->min_cov_len >= max_len) return NIMBLE_OK;
+  uint32_t m = std::max<uint32_t>(max_len, 256);
+  std::vector<uint32_t> t(m + 1, 0xFFFFFFFFu);
+  for (uint32_t L = 1; L <= m; ++L) {
+    // the quotient is monotone in s: binary search over 0 .. 4L (scores never exceed the read length)
+    uint32_t lo = 0, hi = 4 * L + 1;
+    while (lo < hi) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if ((double)mid / (double)L >= percent) hi = mid;
+      else lo = mid + 1;
+    }
+    t[L] = lo <= 4 * L ? lo : 0xFFFFFFFFu;
+  }
+  t[0] = percent <= 0.0 ? 0u : 0xFFFFFFFFu;  // 0/0 is NaN: never >= percent unless the compare is vacuous
+  int rc = upload(c->b_min_cov, t, &c->bytes);
+  if (rc) return rc;
+  c->min_cov_percent = percent;
+  c->min_cov_len = m;
   return NIMBLE_OK;
 }
 
@@ -596,6 +624,8 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc != NIMBLE_OK) return rc;
   rc = ensure_plog(c, max_len);
   if (rc != NIMBLE_OK) return rc;
+  rc = ensure_min_cov(c, p->score_percent, max_len);
+  if (rc != NIMBLE_OK) return rc;
 
   cb.keys = c->b_keys.as<uint64_t>();
   cb.key_hash = c->b_hash.as<uint64_t>();
@@ -613,6 +643,7 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
     cb.dyn_hash[m] = c->b_dyn_hash[m].as<uint64_t>();
     cb.dyn_pos[m] = c->b_dyn_pos[m].as<uint32_t>();
   }
+  cb.min_cov = c->b_min_cov.as<uint32_t>();
   cb.scratch = c->b_scratch.as<uint32_t>();
   cb.scratch_cap = (uint32_t)c->scratch_cap;
   cb.ws_cols = c->b_ws.as<uint32_t>();

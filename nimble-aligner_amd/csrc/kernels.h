@@ -45,6 +45,7 @@ struct CallBuffers {
   uint32_t *len[2];     // bases per mate
   uint64_t *key_hash;   // hash of (total length, packed words)
   uint8_t *pre[2];      // prefilter verdict per mate: ShortRead / HighEntropy / R_TODO
+  const uint32_t *min_cov;  // [len] -> smallest score with score/len >= score_percent in IEEE double
   uint8_t *reason[2];
   uint32_t *score[2];
   uint32_t *mism[2];

@@ -223,6 +223,17 @@ __device__ __forceinline__ uint32_t nr_exts(const NodeRec &r) { return r.q0.x >>
 __device__ __forceinline__ uint4 nr_desc(const NodeRec &r) { return make_uint4(r.q0.w, r.q1.x, r.q1.y, r.q1.z); }
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
+// One-touch streams (packed keys in, per-read results out) use the non-temporal hint so that they do not push
+// the re-used node records out of the XCD's L2.  (Measured: the hint on dictionary / filter gathers is a
+// loss -- those live in the Infinity Cache and want the default policy.)
+#ifdef NIMBLE_NO_NT
+__device__ __forceinline__ uint64_t ld_stream(const uint64_t *p) { return *p; }
+template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { *p = v; }
+#else
+__device__ __forceinline__ uint64_t ld_stream(const uint64_t *p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#endif
+
 // nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
 __device__ __forceinline__ uint64_t lds_bits(const uint64_t *rd, uint32_t pos, uint32_t nb) {
   uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
@@ -612,8 +623,10 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
 #ifndef NIMBLE_ALIGN_WAVES
 #define NIMBLE_ALIGN_WAVES 8
 #endif
-__global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p, CallBuffers cb,
-                                                       int want_counters) {
+template <bool PAIRED, bool COUNTERS>
+__global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p,
+                                                                           CallBuffers cb) {
+  constexpr int want_counters = COUNTERS ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
   const uint32_t tid = threadIdx.x;
   const uint32_t kw = cb.key_words;
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   ln.all_mask = true;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
-  const int nm = cb.paired ? 2 : 1;
+  constexpr int nm = PAIRED ? 2 : 1;
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
 
   // tile slot lives behind the columns in the dynamic region (keeps the extern base 16-byte aligned)
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
       L[0] = cb.len[0][r];
       if (nm == 2) L[1] = cb.len[1][r];
       uint32_t nw = (L[0] + L[1] + 31u) >> 5;
-      for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? cb.keys[(uint64_t)w * n + r] : 0ULL;
+      for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * n + r) : 0ULL;
       col[kw * ALIGN_BLOCK] = 0ULL;
     }
     bool any_walk = false;
@@ -686,10 +699,11 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
             best_len = ln.min_len;
             if (ln.n_cols == 1) count = best_len;
             else count = finish_class(ix, ln, dhash, nullptr, mres);
-            double normalized = (double)cov / (double)L[m];
+            // `score as f64 / len as f64 >= score_percent` (align.rs:968, filter/align.rs:16) as an exact
+            // integer test: min_cov[len] is the smallest score whose IEEE quotient reaches score_percent
             if (p.discard_nonzero_mismatch && mis != 0) {
               reason = NIMBLE_R_DISCARDED_NONZERO_MISMATCH;
-            } else if ((uint64_t)cov >= p.score_threshold && normalized >= p.score_percent && count != 0) {
+            } else if ((uint64_t)cov >= p.score_threshold && cov >= cb.min_cov[L[m]] && count != 0) {
               if (p.discard_multiple_matches && count > 1) reason = NIMBLE_R_DISCARDED_MULTIPLE_MATCH;
               else if (mis > p.num_mismatches) reason = NIMBLE_R_ABOVE_MISMATCH_THRESHOLD;
               else {
@@ -749,10 +763,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
         }
       }
       if (active) {
-        cb.reason[m][r] = (uint8_t)reason;
-        cb.score[m][r] = score;
-        cb.mism[m][r] = mm;
-        cb.cls[m][r] = cls;
+        st_stream(&cb.reason[m][r], (uint8_t)reason);
+        st_stream(&cb.score[m][r], score);
+        st_stream(&cb.mism[m][r], mm);
+        st_stream(&cb.cls[m][r], cls);
       }
     }
     if (any_walk) c_seeded++;
@@ -971,14 +985,21 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
     int per_cu = 0, dev = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align, ALIGN_BLOCK, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align<true, true>, ALIGN_BLOCK, lds) != hipSuccess ||
+        per_cu < 1)
       per_cu = 4;
     if (cus < 1) cus = 256;
     int g = per_cu * cus;
     resident_cache[key] = g > ALIGN_GRID ? ALIGN_GRID : g;
   }
   uint32_t grid = (uint32_t)(tiles < (uint64_t)resident_cache[key] ? tiles : (uint64_t)resident_cache[key]);
-  hipLaunchKernelGGL(k_align, dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb, want_counters);
+  if (cb.paired) {
+    if (want_counters) hipLaunchKernelGGL((k_align<true, true>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+    else hipLaunchKernelGGL((k_align<true, false>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+  } else {
+    if (want_counters) hipLaunchKernelGGL((k_align<false, true>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+    else hipLaunchKernelGGL((k_align<false, false>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+  }
 }
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
