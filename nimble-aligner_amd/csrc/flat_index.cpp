@@ -210,16 +210,19 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     out.ht[2 * h] = kmers[i];
     out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
   }
-  // presence filter: 7 bits per k-mer, sized for <= 8 % density (the 24 shared bits allow up to 2^24 lines)
+  // presence filter: 2 bits in each of 7 lines per k-mer, sized for <= ~16 % bit density, i.e. a false
+  // positive rate of ~2.5 % per position (the 24 shared bits allow up to 2^24 lines)
   out.bm_lines_log2 = 8;
-  while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND > 0.08 * 128.0 * (double)(1ull << out.bm_lines_log2))
+  while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND * 2.0 > 0.16 * 128.0 * (double)(1ull << out.bm_lines_log2))
     ++out.bm_lines_log2;
   out.bitmap.assign((size_t)4 << out.bm_lines_log2, 0);
   for (size_t i = 0; i < n; ++i) {
-    const uint32_t bit = round_bit(kmers[i]);
+    const uint32_t bits = round_bits(kmers[i]);
+    const uint32_t b1 = bits & 127u, b2 = (bits >> 7) & 127u;
     for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
       const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
-      out.bitmap[line * 4 + (bit >> 5)] |= 1u << (bit & 31);
+      out.bitmap[line * 4 + (b1 >> 5)] |= 1u << (b1 & 31);
+      out.bitmap[line * 4 + (b2 >> 5)] |= 1u << (b2 & 31);
     }
   }
   // 7. class descriptors

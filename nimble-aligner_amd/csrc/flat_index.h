@@ -44,16 +44,17 @@ NIMBLE_HD uint64_t kmer_slot(uint64_t km, uint32_t log2_slots) {
 // Round-anchored presence filter.  A seed scan looks at SCAN_ROUND = 7 positions p, p+3, .., p+18 per
 // round; the 7 k-mers of a round share the 12 bases [p+18, p+30).  Those 24 bits select a 128-bit filter
 // line, the k-mer itself selects the bit inside the line, so ONE 16-byte load answers a whole round.
-// At build time every indexed k-mer sets its bit in the 7 lines it can be asked under (slot j of a round
+// At build time every indexed k-mer sets its two bits in the 7 lines it can be asked under (slot j of a round
 // <-> shared bases at offset 3(6-j) of the k-mer).
 constexpr uint32_t SCAN_ROUND = 7;
 constexpr uint32_t SCAN_SHARED = 30 - 3 * (SCAN_ROUND - 1);  // 12 bases
 NIMBLE_HD uint64_t round_line(uint64_t shared, uint32_t lines_log2) {
   return (uint64_t)(((uint32_t)shared * 0x85EBCA6Bu) >> (32u - lines_log2));
 }
-NIMBLE_HD uint32_t round_bit(uint64_t km) {  // 0..127
+// two filter bits per k-mer (Bloom k = 2 inside the 128-bit line): bits [0,7) and [7,14) of the result
+NIMBLE_HD uint32_t round_bits(uint64_t km) {
   const uint32_t f = (uint32_t)km ^ (uint32_t)(km >> 31);
-  return (f * 0xC2B2AE35u) >> 25;
+  return (f * 0xC2B2AE35u) >> 18;  // 14 bits
 }
 // the shared bases of k-mer km when it sits in slot j of a round
 NIMBLE_HD uint64_t round_shared_of_kmer(uint64_t km, uint32_t j) {

@@ -20,6 +20,8 @@
 // words from the (L2 / Infinity-Cache resident) index.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "flat_index.h"
 #include "kernels.h"
 
@@ -30,7 +32,8 @@ namespace {
 constexpr int PACK_BLOCK = 256;
 constexpr int ALIGN_BLOCK = 256;
 constexpr int ALIGN_GRID = 2048;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
-constexpr int LDS_COLS = 6;
+constexpr int LDS_COLS = 4;
+constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds
 constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -281,12 +284,29 @@ __device__ __noinline__ uint64_t ht_resolve_slow(const uint4 *__restrict__ ht, u
   }
 }
 
+// one direct dictionary probe at mate position pos
+__device__ __forceinline__ bool probe_direct(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t pos, uint32_t &node,
+                                             uint32_t &off) {
+  const uint64_t km = lds_bits(ln.rd, base0 + pos, KMER);
+  const uint64_t h = kmer_slot(km, ix.ht_log2);
+  const uint4 s = ix.ht[h];
+  const uint64_t key = u64of(s.x, s.y);
+  ln.probes++;
+  if (key == km) { off = s.z; node = s.w; return true; }
+  if (key != HT_EMPTY) {
+    const uint64_t v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
+    if (v != HT_EMPTY) { off = (uint32_t)v; node = (uint32_t)(v >> 32); return true; }
+  }
+  return false;
+}
+
 // seed search with stride 3 from kmer_pos (positions relative to the mate).  The first probe goes alone
 // (it hits for most on-target reads); after a miss PROBE_BATCH independent probes are kept in flight.
 __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
-                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off) {
+                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off,
+                                           bool skip_direct = false) {
   if (kmer_pos > last_kmer_pos) return false;
-  {
+  if (!skip_direct) {
     const uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
     const uint64_t h = kmer_slot(km, ix.ht_log2);
     const uint4 s = ix.ht[h];
@@ -313,9 +333,11 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
       const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
 #pragma unroll
       for (int i = 0; i < (int)SCAN_ROUND; ++i) {
-        const uint32_t b = round_bit(km);
-        const uint32_t w = (b >> 5) == 0 ? line.x : ((b >> 5) == 1 ? line.y : ((b >> 5) == 2 ? line.z : line.w));
-        maybe |= ((w >> (b & 31u)) & 1u) << i;
+        const uint32_t bb = round_bits(km);
+        const uint32_t b1 = bb & 127u, b2 = (bb >> 7) & 127u;
+        const uint32_t w1 = (b1 >> 5) == 0 ? line.x : ((b1 >> 5) == 1 ? line.y : ((b1 >> 5) == 2 ? line.z : line.w));
+        const uint32_t w2 = (b2 >> 5) == 0 ? line.x : ((b2 >> 5) == 1 ? line.y : ((b2 >> 5) == 2 ? line.z : line.w));
+        maybe |= ((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) << i;
         if (i + 1 < (int)SCAN_ROUND) {
           const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
           km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
@@ -323,37 +345,35 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
       }
     }
     const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
+    const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
+    maybe &= (1u << nvalid) - 1u;
+    uint32_t examined = nvalid;
     bool found = false;
-    uint32_t fpos = 0;
-#pragma unroll
-    for (int i = 0; i < (int)SCAN_ROUND; ++i) {
-      if (!found && 3u * i <= valid) {
-        ln.probes++;
-        if ((maybe >> i) & 1u) {  // rare after a first miss: filter false positive or a real seed
-          const uint32_t p = kmer_pos + 3u * i;
-          const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
-          const uint64_t h = kmer_slot(km, ix.ht_log2);
-          const uint4 sl = ix.ht[h];
-          const uint64_t key = u64of(sl.x, sl.y);
-          uint64_t v = u64of(sl.z, sl.w);
-          bool hit = key == km;
-          if (!hit && key != HT_EMPTY) {
-            v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
-            hit = v != HT_EMPTY;
-          }
-          if (hit) {
-            found = true;
-            fpos = p;
-            off = (uint32_t)v;
-            node = (uint32_t)(v >> 32);
-          }
-        }
+    while (maybe) {  // candidates in read order (filter false positives or a real seed); usually none
+      const uint32_t i = (uint32_t)__ffs((int)maybe) - 1u;
+      maybe &= maybe - 1u;
+      const uint32_t p = kmer_pos + 3u * i;
+      const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
+      const uint64_t h = kmer_slot(km, ix.ht_log2);
+      const uint4 sl = ix.ht[h];
+      const uint64_t key = u64of(sl.x, sl.y);
+      uint64_t v = u64of(sl.z, sl.w);
+      bool hit = key == km;
+      if (!hit && key != HT_EMPTY) {
+        v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
+        hit = v != HT_EMPTY;
+      }
+      if (hit) {
+        found = true;
+        examined = i + 1u;
+        kmer_pos = p;
+        off = (uint32_t)v;
+        node = (uint32_t)(v >> 32);
+        maybe = 0;
       }
     }
-    if (found) {
-      kmer_pos = fpos;
-      return true;
-    }
+    ln.probes += examined;  // the reference examines positions one by one up to the first hit
+    if (found) return true;
     kmer_pos += 3u * SCAN_ROUND;
   }
   return false;
@@ -459,9 +479,16 @@ __device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const NodeRec &nr, c
   return matched;
 }
 
-// map_read_to_nodes_with_mismatch for the mate occupying key bases [base0, base0 + L)
+// map_read_to_nodes_with_mismatch for the mate occupying key bases [base0, base0 + L).
+//
+// Same walk as the reference's (seed search, optional left extension, forward loop with re-seeding), laid out
+// as alternating phases so that a wave does not pay for scan rounds on every walk iteration: lanes that need
+// a seed scan together (SEED phase), then every seeded lane walks until it ends or needs the next seed
+// (WALK phase); a typical read goes through 1-3 cycles.
+// pre: result of a direct probe of position 0 already made for this mate (by the tile partition step):
+// 0 = none made, 1 = miss, 2 = hit with pre_seed = node << 32 | offset
 __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed, uint32_t &coverage,
-                     uint32_t &mismatches) {
+                     uint32_t &mismatches, uint32_t pre, uint64_t pre_seed) {
   ln.n_cols = 0;
   ln.walk_nodes = 0;
   if (L < KMER) return false;
@@ -470,35 +497,50 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   uint32_t kmer_pos = 0;
   const uint32_t last_kmer_pos = L - KMER;
   uint32_t node = 0, koff = 0;
-  bool have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff);
-
-  if (have && kmer_pos >= left_thr) {  // left extension
-    uint32_t last_pos = kmer_pos - 1;
-    uint32_t pnode = node;
-    uint32_t poff = koff > 0 ? koff - 1 : 0;
-    for (;;) {
-      NodeRec nr = load_node(ix, pnode);
-      uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
-      bool prem;
-      uint32_t matched = cmp_bwd(ln, nr, ix.unitig, base0 + last_pos, poff, n, allowed, mm, prem);
-      cov += matched;
-      if (last_pos + 1 - matched == 0 || prem) break;
-      last_pos -= matched;
-      uint32_t nbase = lds_base(ln.rd, base0 + last_pos);
-      if (nr_exts(nr) & (1u << nbase)) {
-        uint4 le = ix.node_ledge[pnode];
-        pnode = sel4(le, nbase);
-        const uint4 h0 = ix.node_rec[(size_t)pnode * 4], h1 = ix.node_rec[(size_t)pnode * 4 + 1];
-        poff = (h0.x & 0xFFFFFFu) - KMER;
-        push_col(ln, h0.y, make_uint4(h0.w, h1.x, h1.y, h1.z));
+  bool first = true, done = false, need_seed = true;
+  do {
+    if (need_seed) {  // SEED phase
+      need_seed = false;
+      bool have;
+      if (first && pre == 2u) {
+        have = true;
+        node = (uint32_t)(pre_seed >> 32);
+        koff = (uint32_t)pre_seed;
+      } else if (first && pre == 1u) {
+        kmer_pos = 3;
+        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, true);
       } else {
-        break;
+        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff);
       }
+      if (!have) {
+        done = true;
+      } else if (first && kmer_pos >= left_thr) {  // left extension, only behind a late first seed
+        uint32_t last_pos = kmer_pos - 1;
+        uint32_t pnode = node;
+        uint32_t poff = koff > 0 ? koff - 1 : 0;
+        for (;;) {
+          NodeRec nr = load_node(ix, pnode);
+          uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
+          bool prem;
+          uint32_t matched = cmp_bwd(ln, nr, ix.unitig, base0 + last_pos, poff, n, allowed, mm, prem);
+          cov += matched;
+          if (last_pos + 1 - matched == 0 || prem) break;
+          last_pos -= matched;
+          uint32_t nbase = lds_base(ln.rd, base0 + last_pos);
+          if (nr_exts(nr) & (1u << nbase)) {
+            uint4 le = ix.node_ledge[pnode];
+            pnode = sel4(le, nbase);
+            const uint4 h0 = ix.node_rec[(size_t)pnode * 4], h1 = ix.node_rec[(size_t)pnode * 4 + 1];
+            poff = (h0.x & 0xFFFFFFu) - KMER;
+            push_col(ln, h0.y, make_uint4(h0.w, h1.x, h1.y, h1.z));
+          } else {
+            break;
+          }
+        }
+      }
+      first = false;
     }
-  }
-  if (kmer_pos <= last_kmer_pos) {  // forward search (a seed was found)
-
-    for (;;) {
+    while (!done && !need_seed) {  // WALK phase: one unitig per iteration
       NodeRec nr = load_node(ix, node);
       kmer_pos += KMER;
       cov += KMER;
@@ -512,26 +554,28 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
       if (n) matched = cmp_fwd(ln, nr, ix.unitig, base0 + kmer_pos, ref_off, n, allowed, mm, prem);
       cov += matched;
       kmer_pos += matched;
-      if (kmer_pos >= L) break;
-      uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
-      if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
-        node = sel4(nr.re, nbase);
-        koff = 0;
-        kmer_pos -= KMER - 1;
-        cov -= KMER - 1;
+      if (kmer_pos >= L) {
+        done = true;
       } else {
-        if (kmer_pos > last_kmer_pos) break;
-        if (!find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff)) break;
+        uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
+        if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
+          node = sel4(nr.re, nbase);
+          koff = 0;
+          kmer_pos -= KMER - 1;
+          cov -= KMER - 1;
+        } else if (kmer_pos > last_kmer_pos) {
+          done = true;
+        } else {
+          need_seed = true;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
+        }
       }
     }
-  }
+  } while (!done);
   if (ln.walk_nodes == 0) return false;
   coverage = cov;
   mismatches = mm;
   return true;
 }
-
-// class table access ------------------------------------------------------------------------------
 
 // general form of nodes_to_eq_class (some visited class spans 64 rows or more): smallest class first,
 // membership test of each of its rows in every other visited class.  Everything is passed and returned by
@@ -650,10 +694,13 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   constexpr int nm = PAIRED ? 2 : 1;
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
 
-  // tile slot lives behind the columns in the dynamic region (keeps the extern base 16-byte aligned)
-  unsigned long long &s_tile =
-      *reinterpret_cast<unsigned long long *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) +
-                                              LDS_COLS * ALIGN_BLOCK);
+  // small block-shared arrays behind the columns in the dynamic region (extern base stays 16-byte aligned)
+  uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) +
+                                               LDS_COLS * ALIGN_BLOCK);
+  unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
+  uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
+  uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
   for (;;) {
     // dynamic tile scheduling: tiles differ a lot in cost (off-target reads probe 41 times)
     __syncthreads();
@@ -661,15 +708,64 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
     __syncthreads();
     const uint64_t tile = s_tile;
     if (tile >= n_tiles) break;
-    const uint64_t r = tile * ALIGN_BLOCK + tid;
+    // ---- own slot: key into LDS column tid, first direct probe of mate 0
+    const uint64_t r_own = tile * ALIGN_BLOCK + tid;
+    uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
+    uint64_t seedv = ~0ULL;
+    if (r_own < n) {
+      const uint32_t l0 = cb.len[0][r_own];
+      const uint32_t l1 = nm == 2 ? cb.len[1][r_own] : 0u;
+      const uint32_t nw = (l0 + l1 + 31u) >> 5;
+      for (uint32_t w = 0; w < kw; ++w)
+        col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * n + r_own) : 0ULL;
+      col[kw * ALIGN_BLOCK] = 0ULL;
+      if (cb.pre[0][r_own] == R_TODO && l0 >= KMER) {
+        uint32_t nd = 0, of = 0;
+        ln.rd = col;
+        if (probe_direct(ix, ln, 0u, 0u, nd, of)) {
+          kind = 1;
+          seedv = u64of(of, nd);
+        } else {
+          kind = 0;
+        }
+      }
+    }
+    // ---- partition the tile: reads that still need a scan first, then the seeded ones, then the rest, so
+    // that the waves of the block are (nearly) homogeneous and most of them skip the scan rounds entirely
+    s_seed[tid] = seedv;
+    {
+      const uint64_t b0 = __ballot(kind == 0), b1 = __ballot(kind == 1);
+      const uint32_t wv = tid >> 6, lane = tid & 63u;
+      if (lane == 0) {
+        s_cnt[wv * 2] = (uint32_t)__popcll(b0);
+        s_cnt[wv * 2 + 1] = (uint32_t)__popcll(b1);
+      }
+      __syncthreads();
+      uint32_t tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < ALIGN_BLOCK / 64; ++w) {
+        const uint32_t c0 = s_cnt[w * 2], c1 = s_cnt[w * 2 + 1];
+        if (w < wv) { pre0 += c0; pre1 += c1; }
+        tot0 += c0;
+        tot1 += c1;
+      }
+      const uint64_t below = (1ULL << lane) - 1ULL;
+      const uint32_t r0 = (uint32_t)__popcll(b0 & below), r1 = (uint32_t)__popcll(b1 & below);
+      const uint32_t r2 = lane - r0 - r1;                       // rank among kind 2 in this wave
+      const uint32_t pre2 = wv * 64u - pre0 - pre1;             // kind-2 lanes in earlier waves
+      const uint32_t pos = kind == 0 ? pre0 + r0 : (kind == 1 ? tot0 + pre1 + r1 : tot0 + tot1 + pre2 + r2);
+      s_perm[pos] = (uint16_t)tid;
+      __syncthreads();
+    }
+    const uint32_t slot = s_perm[tid];
+    const uint64_t r = tile * ALIGN_BLOCK + slot;
     const bool active = r < n;
+    ln.rd = lds64 + slot;
+    const uint64_t pre_seed = s_seed[slot];
     uint32_t L[2] = {0, 0};
     if (active) {
       L[0] = cb.len[0][r];
       if (nm == 2) L[1] = cb.len[1][r];
-      uint32_t nw = (L[0] + L[1] + 31u) >> 5;
-      for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * n + r) : 0ULL;
-      col[kw * ALIGN_BLOCK] = 0ULL;
     }
     bool any_walk = false;
     for (int m = 0; m < nm; ++m) {
@@ -687,7 +783,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
           if (m == 0) c_pre++;
         } else {
           uint32_t cov = 0, mis = 0;
-          bool some = walk(ix, ln, m ? L[0] : 0u, L[m], p.num_mismatches, cov, mis);
+          const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
+          bool some = walk(ix, ln, m ? L[0] : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed);
           if (!some) {
             reason = NIMBLE_R_NO_MATCH;
           } else {
@@ -976,7 +1073,7 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                   int want_counters) {
   if (cb.n == 0) return;
   uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + 16;
+  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter
   static int resident_cache[64] = {0};
