@@ -386,9 +386,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   const uint64_t islots = pow2_at_least(4 * cls_cap);
   std::vector<uint64_t> intern(islots, 0);
   for (size_t c = 0; c < fi.n_colours; ++c) {
-    uint64_t h = class_hash_init();
-    for (uint32_t t = fi.col_off[c]; t < fi.col_off[c + 1]; ++t) h = class_hash_step(h, fi.col_ids[t]);
-    h = class_hash_final(h, len[c]);
+    const uint64_t h = class_hash_of_ids(fi.col_ids.data() + fi.col_off[c], len[c]);
     uint64_t pos = h & (islots - 1);
     while (intern[pos] != 0) pos = (pos + 1) & (islots - 1);
     intern[pos] = ((uint64_t)intern_tag(h) << 32) | (uint32_t)c;
@@ -411,6 +409,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
+  d.all_local = fi.all_classes_local ? 1u : 0u;
   d.cls_desc = ix->b_cls_desc.as<uint4>();
   d.cls_off = ix->b_cls_off.as<uint32_t>();
   d.cls_ids = ix->b_cls_ids.as<uint32_t>();

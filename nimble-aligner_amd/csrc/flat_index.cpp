@@ -230,6 +230,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   for (size_t c = 0; c < out.n_colours; ++c) {
     uint32_t o = out.col_off[c], l = out.col_off[c + 1] - o;
     make_class_desc(out.col_ids.data() + o, l, &out.cls_desc[c * 4]);
+    if (!(out.cls_desc[c * 4] & CLS_MASK_FLAG)) out.all_classes_local = false;
   }
   for (size_t nd = 0; nd < n_nodes; ++nd) {
     const uint32_t c = out.node_rec[nd * 16 + 1];

@@ -69,6 +69,23 @@ NIMBLE_HD uint64_t class_hash_step(uint64_t h, uint32_t id) {
   return h ^ (h >> 29);
 }
 NIMBLE_HD uint64_t class_hash_final(uint64_t h, uint32_t len) { return mix64(h ^ ((uint64_t)len * 0x9FB21C651E98DF25ULL)); }
+// Hash of a class for interning.  A class that fits the mask form (rows within a 64-row window) is hashed
+// from (len, base, mask); any other class from its ids.  Both sides (host seeding, device lookup) apply the
+// same rule, which depends on the content only.
+NIMBLE_HD uint64_t class_hash_mask(uint32_t len, uint32_t base, uint64_t mask) {
+  return mix64(mask ^ (((uint64_t)base << 32) | (uint64_t)len) * 0x9FB21C651E98DF25ULL);
+}
+NIMBLE_HD uint64_t class_hash_of_ids(const uint32_t *ids, uint32_t len) {
+  if (len && ids[len - 1] - ids[0] < 64u) {
+    uint64_t m = 0;
+    for (uint32_t t = 0; t < len; ++t) m |= 1ULL << (ids[t] - ids[0]);
+    return class_hash_mask(len, ids[0], m);
+  }
+  uint64_t h = class_hash_init();
+  for (uint32_t t = 0; t < len; ++t) h = class_hash_step(h, ids[t]);
+  return class_hash_final(h, len);
+}
+
 // DnaString::from_acgt_bytes: A/a C/c G/g T/t -> 0..3, everything else -> 0
 NIMBLE_HD uint32_t encode_base(uint32_t c) {
   uint32_t l = c | 0x20u;
@@ -130,6 +147,7 @@ struct FlatIndex {
   // intersection of visited colours is one 16-byte load per colour plus shift/AND.  Classes that span 64
   // rows or more keep len without the flag and are intersected through the CSR ids.
   std::vector<uint32_t> cls_desc;    // 4 x u32 per class
+  bool all_classes_local = true;     // every static class has the mask form
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };
 

@@ -28,6 +28,7 @@ struct DevIndex {
   uint4 *cls_desc;          // {len | CLS_MASK_FLAG, base, mask lo, mask hi}
   uint32_t *cls_off;        // offset of the class in cls_ids (CSR form, every class has it)
   uint32_t *cls_ids;
+  uint32_t all_local;       // every static class is in mask form: no colour list is kept during the walk
   uint32_t n_static;
   uint32_t cls_cap;       // capacity in classes
   uint32_t ids_cap;       // capacity of cls_ids

@@ -198,6 +198,7 @@ struct Lane {
   uint64_t acc;
   uint32_t fbase, min_len, min_col;
   bool all_mask;
+  bool keep_list;  // some class of the index is not local: keep the visited colours for the general path
   uint32_t probes, nodes;
   uint64_t entries;
   int want_counters;
@@ -391,14 +392,13 @@ __device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base
   return -delta < 64 ? (m >> (-delta)) : 0ULL;
 }
 
-// a visited node: counters, running intersection, and the colour list kept for the general (non-mask) path
+// a visited node: counters, running mask intersection and, only when the index has non-local classes, the
+// colour list for the general path
 __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 &desc) {
   ln.nodes++;
-  ln.walk_nodes++;
   if (ln.want_counters) ln.entries += desc_len(desc);
-  if (ln.n_cols && colour == ln.last_col) return;  // intersection is idempotent
   const uint32_t l = desc_len(desc);
-  if (ln.n_cols == 0) {
+  if (ln.walk_nodes == 0) {
     ln.fbase = desc.y;
     ln.acc = ~0ULL;
     ln.all_mask = true;
@@ -408,19 +408,23 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 
     ln.min_len = l;
     ln.min_col = colour;
   }
-  ln.all_mask = ln.all_mask && desc_is_mask(desc);
-  ln.acc &= mask_in_window(desc, ln.fbase);
-  uint32_t j = ln.n_cols;
-  ln.last_col = colour;
-  if (j < LDS_COLS) {
-    ln.lc[j * ALIGN_BLOCK] = colour;
-  } else if (j - LDS_COLS < ln.ws_rows) {
-    ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes] = colour;
-  } else {
-    ln.overflow = 1;
-    return;
+  ln.walk_nodes++;
+  ln.acc &= mask_in_window(desc, ln.fbase);  // idempotent: repeated colours cost nothing
+  if (ln.keep_list) {
+    ln.all_mask = ln.all_mask && desc_is_mask(desc);
+    if (ln.n_cols && colour == ln.last_col) return;
+    uint32_t j = ln.n_cols;
+    ln.last_col = colour;
+    if (j < LDS_COLS) {
+      ln.lc[j * ALIGN_BLOCK] = colour;
+    } else if (j - LDS_COLS < ln.ws_rows) {
+      ln.ws[(uint64_t)(j - LDS_COLS) * ln.ws_lanes] = colour;
+    } else {
+      ln.overflow = 1;
+      return;
+    }
+    ln.n_cols = j + 1;
   }
-  ln.n_cols = j + 1;
 }
 
 // compare n bases forward: key[rpos + i] vs unitig[upos + i] (upos node-relative).  Returns the bases
@@ -588,7 +592,8 @@ __device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint
                                                const uint32_t *lc, const uint32_t *ws, uint32_t ws_lanes,
                                                uint32_t n_cols, uint32_t best, uint32_t bl, uint32_t *out) {
   const uint32_t *bids = cls_ids + cls_off[best];
-  uint32_t count = 0;
+  uint32_t count = 0, first_id = 0, last_id = 0;
+  uint64_t gmask = 0;
   uint64_t h = class_hash_init();
   for (uint32_t t = 0; t < bl; ++t) {
     const uint32_t id = bids[t];
@@ -615,12 +620,16 @@ __device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint
     if (ok) {
       if (out) out[count] = id;
       h = class_hash_step(h, id);
+      if (count == 0) first_id = id;
+      last_id = id;
+      if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
       ++count;
     }
   }
   IRes r;
   r.count = count;
   r.hash = class_hash_final(h, count);
+  if (count && last_id - first_id < 64u) r.hash = class_hash_mask(count, first_id, gmask);  // mask-form rule
   return r;
 }
 
@@ -649,15 +658,11 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
     mr.base = ln.fbase + tz;
     mr.mask = acc >> tz;
   }
-  uint64_t h = class_hash_init();
-  uint32_t k = 0;
-  for (uint64_t m = acc; m; m &= m - 1) {
-    const uint32_t id = ln.fbase + (uint32_t)__ffsll((long long)m) - 1u;
-    if (out) out[k] = id;
-    h = class_hash_step(h, id);
-    ++k;
+  hash = class_hash_mask(count, mr.base, mr.mask);
+  if (out) {
+    uint32_t k = 0;
+    for (uint64_t m = acc; m; m &= m - 1) out[k++] = ln.fbase + (uint32_t)__ffsll((long long)m) - 1u;
   }
-  hash = class_hash_final(h, count);
   return count;
 }
 
@@ -689,6 +694,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   ln.acc = 0;
   ln.fbase = ln.min_len = ln.min_col = 0;
   ln.all_mask = true;
+  ln.keep_list = ix.all_local == 0;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
   constexpr int nm = PAIRED ? 2 : 1;
@@ -794,8 +800,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
             uint32_t count;
             best_col = ln.min_col;
             best_len = ln.min_len;
-            if (ln.n_cols == 1) count = best_len;
-            else count = finish_class(ix, ln, dhash, nullptr, mres);
+            count = finish_class(ix, ln, dhash, nullptr, mres);
             // `score as f64 / len as f64 >= score_percent` (align.rs:968, filter/align.rs:16) as an exact
             // integer test: min_cov[len] is the smallest score whose IEEE quotient reaches score_percent
             if (p.discard_nonzero_mismatch && mis != 0) {
