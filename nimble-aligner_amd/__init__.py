@@ -7,6 +7,9 @@ compute and no fallback: if the library is missing, importing the device classes
 
 The directory name has a hyphen, so import it with
 ``importlib.import_module("nimble-aligner_amd")``.
+
+When torch is used in the same process (device buffers, torch.distributed), import torch BEFORE the first call
+into this module: torch bundles its own HIP runtime and must be the first one loaded.
 """
 import ctypes as C
 import os

@@ -120,9 +120,12 @@ struct nimble_ctx {
   const uint64_t *in_off[2] = {nullptr, nullptr};
   uint32_t in_fixed_len = 0, in_max_len = 0;
   uint64_t dslots = 0;
+  uint64_t dedup_clean_slots = 0;  // slots [0, this) of b_dedup are known to be zero (cleared at the tail of the last call)
   bool finished = true;
   int attempt = 0;
   std::vector<uint64_t> h_state = std::vector<uint64_t>(16, 0);
+  std::vector<uint32_t> h_c1, h_c2;  // histogram of the last finished call, sorted by (c1, c2)
+  std::vector<uint64_t> h_cnt;
   ~nimble_ctx() {
     for (DevBuf *b : {&b_keys, &b_len[0], &b_len[1], &b_hash, &b_pre[0], &b_pre[1], &b_reason[0], &b_reason[1],
                       &b_score[0], &b_score[1], &b_mism[0], &b_mism[1], &b_cls[0], &b_cls[1], &b_dyn_off[0],
@@ -218,7 +221,8 @@ int enqueue_call(nimble_ctx *c) {
   CallBuffers &cb = c->cb;
   const size_t nn = std::max<uint64_t>(cb.n, 1);
   HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
-  HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
+  if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
+  c->dedup_clean_slots = 0;
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
   if (!cb.paired) HIPCHK(hipMemsetAsync(c->b_len[1].p, 0, nn * 4, s));
@@ -309,6 +313,34 @@ int finish_call(nimble_ctx *c) {
       continue;
     }
     break;
+  }
+  // histogram entries to the host (sorted by class pair), then clear the dedup table for the next call: the
+  // memset runs on the stream while the host turns the histogram into rows
+  {
+    const uint64_t ne = c->h_state[11];
+    c->h_c1.resize(ne);
+    c->h_c2.resize(ne);
+    c->h_cnt.resize(ne);
+    if (ne) {
+      std::vector<uint32_t> a(ne), b(ne);
+      std::vector<uint64_t> k(ne);
+      HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      std::vector<uint64_t> order(ne);
+      for (uint64_t i = 0; i < ne; ++i) order[i] = ((uint64_t)a[i] << 32) | b[i];
+      std::vector<uint32_t> idx(ne);
+      for (uint64_t i = 0; i < ne; ++i) idx[i] = (uint32_t)i;
+      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return order[x] < order[y]; });
+      for (uint64_t i = 0; i < ne; ++i) {
+        c->h_c1[i] = a[idx[i]];
+        c->h_c2[i] = b[idx[i]];
+        c->h_cnt[i] = k[idx[i]];
+      }
+    }
+    HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, c->stream));
+    c->dedup_clean_slots = c->dslots;
   }
   c->finished = true;
   return NIMBLE_OK;
@@ -614,8 +646,12 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   need(c->b_scratch, c->scratch_cap * 4);
   const uint32_t ws_rows = max_len > align_lds_cols() ? max_len - align_lds_cols() : 0;
   need(c->b_ws, std::max<size_t>((size_t)ws_rows * align_ws_lanes() * 4, 16));
-  const uint64_t dslots = pow2_at_least(std::max<uint64_t>(2 * n, 1024));
-  need(c->b_dedup, dslots * 8);
+  const uint64_t dslots = std::max<uint64_t>(n + n / 2, 1024);  // load factor <= 2/3 even if every read is kept
+  {
+    const void *before = c->b_dedup.p;
+    need(c->b_dedup, dslots * 8);
+    if (c->b_dedup.p != before) c->dedup_clean_slots = 0;
+  }
   if (c->hist_slots == 0) c->hist_slots = pow2_at_least(env_u64("NIMBLE_HIST_SLOTS", 1ULL << 20));
   need(c->b_hist_keys, c->hist_slots * 8);
   need(c->b_hist_cnt, c->hist_slots * 8);
@@ -649,7 +685,7 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   cb.ws_rows = ws_rows;
   cb.ws_lanes = align_ws_lanes();
   cb.dedup = c->b_dedup.as<uint64_t>();
-  cb.dedup_mask = dslots - 1;
+  cb.dedup_slots = (uint32_t)dslots;
   cb.hist_keys = c->b_hist_keys.as<uint64_t>();
   cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
   cb.hist_mask = c->hist_slots - 1;
@@ -686,25 +722,14 @@ int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = finish_count_stage(c);
   if (rc) return rc;
-  const uint64_t ne = c->h_state[11];
+  const uint64_t ne = c->h_cnt.size();
   *n_entries = ne;
   if (cap == 0 || ne == 0) return NIMBLE_OK;
   if (!class_r1 || !class_r2 || !count) return fail(NIMBLE_E_INVALID, "nimble_histogram: NULL output");
-  std::vector<uint32_t> a(ne), b(ne);
-  std::vector<uint64_t> k(ne);
-  HIPCHK(hipMemcpy(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost));
-  std::vector<uint64_t> order(ne);
-  for (uint64_t i = 0; i < ne; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
-    return a[x] != a[y] ? a[x] < a[y] : b[x] < b[y];
-  });
-  for (uint64_t i = 0; i < ne && i < cap; ++i) {
-    class_r1[i] = a[order[i]];
-    class_r2[i] = b[order[i]];
-    count[i] = k[order[i]];
-  }
+  const uint64_t m = std::min(ne, cap);
+  memcpy(class_r1, c->h_c1.data(), m * 4);
+  memcpy(class_r2, c->h_c2.data(), m * 4);
+  memcpy(count, c->h_cnt.data(), m * 8);
   return NIMBLE_OK;
 }
 
@@ -761,11 +786,7 @@ int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
   rc = nimble_histogram(c, nullptr, nullptr, nullptr, 0, &ne);
   if (rc) return rc;
   uint64_t uniq = 0;
-  if (ne) {
-    std::vector<uint64_t> k(ne);
-    HIPCHK(hipMemcpy(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost));
-    for (uint64_t v : k) uniq += v;
-  }
+  for (uint64_t v : c->h_cnt) uniq += v;
   uint32_t dst[4];
   HIPCHK(hipMemcpy(dst, c->ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost));
   out[0] = c->cb.n;

@@ -63,7 +63,7 @@ struct CallBuffers {
   uint32_t ws_rows;
   uint32_t ws_lanes;
   uint64_t *dedup;        // {tag<<32 | read index}, 0 = empty
-  uint64_t dedup_mask;
+  uint32_t dedup_slots;   // not a power of two: slot = mulhi32(hash >> 32, dedup_slots)
   uint64_t *hist_keys;    // (cls1 << 32 | cls2), HIST_EMPTY = empty
   uint64_t *hist_cnt;
   uint64_t hist_mask;

@@ -981,7 +981,7 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
   const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)i;
   const uint32_t total = cb.len[0][i] + (cb.paired ? cb.len[1][i] : 0u);
   const uint32_t nw = (total + 31u) >> 5;
-  uint64_t pos = h & cb.dedup_mask;
+  uint32_t pos = __umulhi((uint32_t)h, cb.dedup_slots);  // low hash half picks the slot, high half is the tag
   for (;;) {
     uint64_t cur = atomicCAS((unsigned long long *)&cb.dedup[pos], 0ULL, (unsigned long long)mine);
     if (cur == 0) break;
@@ -994,7 +994,7 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
         break;
       }
     }
-    pos = (pos + 1) & cb.dedup_mask;
+    pos = pos + 1 == cb.dedup_slots ? 0u : pos + 1;
   }
   cb.slot[i] = (uint32_t)pos;
 }

@@ -178,6 +178,8 @@ def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 <<
 
     cat_np, off_np = _codes(seqs)
     dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.init()  # a Generator on a cuda device does not trigger torch's lazy initialisation
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed + n))
     cat = torch.from_numpy(cat_np).to(dev)

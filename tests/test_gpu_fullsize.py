@@ -1,0 +1,138 @@
+"""GPU parity at BASELINE.json's full sizes, through size-independent properties, plus oracle comparisons at the
+largest sizes the CPU oracle finishes in seconds.
+
+Properties checked at 10 M reads (configs[2]):
+  * idempotence under duplication: call(reads ++ reads) == call(reads)   (dedup by read key, align.rs:576-579,685)
+  * permutation invariance: a shuffled read order gives the same table
+  * conservation: sum of histogram counts == number of counted representatives == unique kept keys
+  * determinism: two calls give identical tables
+  * decomposition: per-feature-family disjoint read sets add up (reads of disjoint key sets -> tables add)
+"""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+nim = importlib.import_module("nimble-aligner_amd")
+synth = importlib.import_module("nimble-aligner_amd.synth")
+HEADERS = ["reference_genome", "sequence_name", "nt_length", "sequence"]
+
+
+@pytest.fixture(scope="module")
+def lib1000():
+    names, seqs = synth.make_library(1000)
+    lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index()
+    return lib, names, seqs
+
+
+def table(lib, t, n):
+    return lib.score_call(t, None, n=n, fixed_len=150, mem=nim.MEM_DEVICE)
+
+
+def test_config2_properties_at_10m_reads(lib1000):
+    torch = pytest.importorskip("torch")
+    lib, names, seqs = lib1000
+    n = 10_000_000
+    reads = synth.make_reads_torch(seqs, n, device="cuda:0")
+    torch.cuda.synchronize()
+    base = table(lib, reads, n)
+    assert len(base) > 1500
+    # determinism
+    assert table(lib, reads, n) == base
+    # conservation: histogram total == representatives == unique kept keys
+    ctx = lib.device_context()
+    ctx.n = n
+    hist = ctx.histogram()
+    rec = ctx.read_records(0)
+    total = sum(c for _, _, c in hist)
+    assert total == int(rec["counted"].sum()) == ctx.counters()["unique_keys"]
+    kept = rec["reason"] == 11
+    assert int(rec["counted"].sum()) <= int(kept.sum())
+    # every row count is positive and rows are sorted by callset
+    assert all(c > 0 for _, c in base) and [f for f, _ in base] == sorted(f for f, _ in base)
+    # permutation invariance
+    perm = torch.randperm(n, device="cuda:0")
+    shuffled = reads[perm].contiguous()
+    torch.cuda.synchronize()
+    assert table(lib, shuffled, n) == base
+    del shuffled, perm
+    # idempotence under duplication (20 M reads in one call)
+    doubled = torch.cat([reads, reads], dim=0).contiguous()
+    torch.cuda.synchronize()
+    assert table(lib, doubled, 2 * n) == base
+    del doubled
+    # decomposition: two halves with disjoint key sets add up (split by a key-content hash)
+    # (the key is the converted base string: N reads as A, so the split must hash the converted bases)
+    conv = torch.where(reads == ord("N"), torch.full_like(reads, ord("A")), reads)
+    h = (conv.to(torch.int64) * torch.arange(1, 151, device="cuda:0")).sum(dim=1)
+    del conv
+    sel = (h % 2) == 0
+    a, b = reads[sel].contiguous(), reads[~sel].contiguous()
+    torch.cuda.synchronize()
+    ta, tb = table(lib, a, a.shape[0]), table(lib, b, b.shape[0])
+    merged = {}
+    for f, c in ta + tb:
+        merged[tuple(f)] = merged.get(tuple(f), 0) + c
+    assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in base]
+
+
+def test_config1_one_million_reads_vs_oracle():
+    # BASELINE.json configs[1]: 1 M x 150 bp single-end vs a 500-feature library, table bit-exact vs the CPU path
+    names, seqs = synth.make_library(500)
+    obj = synth.library_json(names, seqs)
+    lib = nim.Library(text=json.dumps(obj), strand_filter="unstranded").build_index()
+    reads = synth.make_reads(seqs, 1_000_000, seed=4242)
+    got = lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(obj[0], len(names), "unstranded")
+    exp = ora.call(ora.Index.from_reference(ref), ref, cfg, reads.reshape(-1), synth.fixed_offsets(reads.shape[0], 150),
+                   n_threads=8, keep_per_read=True)
+    assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
+    ctx = lib.device_context()
+    ctx.n = reads.shape[0]
+    rec = ctx.read_records(0)
+    np.testing.assert_array_equal(rec["reason"], exp.per_read["reason"][0])
+    np.testing.assert_array_equal(rec["score"], exp.per_read["score"][0])
+    np.testing.assert_array_equal(rec["mismatches"], exp.per_read["mismatches"][0])
+
+
+@pytest.mark.parametrize("nm", [0, 2])
+def test_config3_paired_end_vs_oracle(lib1000, nm):
+    # BASELINE.json configs[3] shape (2 x 150 bp, mismatch.rs tolerance settings) at 400 k pairs
+    lib, names, seqs = lib1000
+    r1, r2 = synth.make_reads(seqs, 400_000, paired=True, seed=31 + nm)
+    over = dict(num_mismatches=nm, score_percent=0.08, score_threshold=12)
+    lib.update_config(**over)
+    o = synth.fixed_offsets(r1.shape[0], 150)
+    try:
+        got = lib.score_call(r1.reshape(-1), o, r2.reshape(-1), o)
+    finally:
+        lib.update_config(num_mismatches=0, score_percent=0.33, score_threshold=50)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(synth.library_json(names, seqs)[0], len(names), "unstranded").copy(**over)
+    exp = ora.call(ora.Index.from_reference(ref), ref, cfg, r1.reshape(-1), o, r2.reshape(-1), o, n_threads=8)
+    assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
+
+
+def test_config4_five_thousand_feature_index():
+    # BASELINE.json configs[4] library size (5 k features, 10 k index rows) on one GPU at 300 k reads
+    names, seqs = synth.make_library(5000)
+    obj = synth.library_json(names, seqs)
+    lib = nim.Library(text=json.dumps(obj), strand_filter="unstranded").build_index()
+    reads = synth.make_reads(seqs, 300_000, seed=99)
+    got = lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(obj[0], len(names), "unstranded")
+    oidx = ora.Index.from_reference(ref)
+    exp = ora.call(oidx, ref, cfg, reads.reshape(-1), synth.fixed_offsets(reads.shape[0], 150), n_threads=8)
+    assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
+    st = nim.Context(borrowed=nim.host_lib().nimble_library_ctx(lib.h))  # context exists
+    assert st.h
