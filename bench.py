@@ -74,7 +74,8 @@ def main():
     def step():
         """One score::call: ends with the sorted rows materialised on the host (C++ result object)."""
         if world > 1:
-            return nd.sharded_call(compute, reads, None, device)
+            # pack locally -> exchange packed records by key hash (all-to-all) -> finish per rank -> all-reduce
+            return nd.sharded_call_packed(lib, reads, None, n, L, device)
         return lib.score_call_raw(reads, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count

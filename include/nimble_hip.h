@@ -120,6 +120,27 @@ int nimble_call(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, co
                 const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len,
                 int mem);
 
+/* ---- split form of the call, for multi-GPU runs: reads are packed where they are, exchanged between
+ *      ranks in packed form (40 B instead of 150 B per read; the key hash that routes them is a function of
+ *      the converted bases, so equal keys meet on one rank), and the rest of the call runs on the receiver.
+ *
+ * All arrays are caller-owned DEVICE memory with n entries (keys: key_words planes of n u64, word-major).
+ * nimble_pack fills them; nimble_call_packed consumes them and must see them alive until the first getter. */
+typedef struct nimble_packed {
+  uint64_t *keys;     /* [key_words][n]: R1 bases ++ R2 bases, 2 bits each, first base in the high bits */
+  uint32_t *len[2];   /* bases per mate (len[1] may be NULL for single-end) */
+  uint64_t *hash;     /* hash of (total length, packed words): dedup and routing key */
+  uint8_t *pre[2];    /* prefilter verdict per mate: NIMBLE_R_SHORT_READ / NIMBLE_R_HIGH_ENTROPY / 255 = align */
+  uint32_t key_words; /* nimble_key_words(max_len, paired) */
+  uint32_t paired;
+} nimble_packed;
+uint32_t nimble_key_words(uint32_t max_len, int paired);
+int nimble_pack(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, const uint64_t *r1_off,
+                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                const nimble_packed *out);
+int nimble_call_packed(nimble_ctx *, const nimble_align_params *, const nimble_packed *in, uint64_t n,
+                       uint32_t max_len);
+
 /* Histogram of the call: one entry per distinct (class of R1, class of R2) over the unique read keys
  * that survived the per-read filters (the `score_map` of src/align.rs:496-505, grouped).
  * class == NIMBLE_CLASS_NONE where that mate has no passing alignment (PairState First/Second).

@@ -13,6 +13,8 @@
 #define NIMBLE_HOST_H
 #include <stdint.h>
 
+#include "nimble_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -65,6 +67,13 @@ void *nimble_library_ctx(nimble_library *);
 int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                       const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                       nimble_rows **out);
+/* split form of score::call for the multi-GPU driver (see nimble_pack / nimble_call_packed in nimble_hip.h):
+ * pack on the rank that holds the reads, exchange the packed arrays, finish on the receiving rank */
+int nimble_library_pack(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                        const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                        const nimble_packed *out);
+int nimble_score_call_packed(nimble_library *, const nimble_packed *in, uint64_t n, uint32_t max_len,
+                             nimble_rows **out);
 /* get_error_checked_fastq_readers + score::call */
 int nimble_score_call_fastq(nimble_library *, const char *r1_path, const char *r2_path, nimble_rows **out);
 void nimble_rows_free(nimble_rows *);

@@ -58,13 +58,22 @@ class AlignParams(C.Structure):
                    int(discard_multiple_matches), int(require_valid_pair), int(min_read_length), 0)
 
 
+class NimblePacked(C.Structure):
+    """nimble_packed (include/nimble_hip.h): caller-owned device arrays of the packed form of a read set."""
+    _fields_ = [
+        ("keys", C.c_void_p), ("len", C.c_void_p * 2), ("hash", C.c_void_p), ("pre", C.c_void_p * 2),
+        ("key_words", C.c_uint32), ("paired", C.c_uint32),
+    ]
+
+
 _hip = None
 
 HIP_SYMBOLS = [
     "nimble_abi_version", "nimble_last_error", "nimble_device_count", "nimble_index_build", "nimble_index_free",
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
-    "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option",
+    "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
+    "nimble_call_packed",
 ]
 
 
@@ -97,6 +106,10 @@ def hip_lib():
         L.nimble_read_records.argtypes = [vp, i32, vp, vp, vp, vp, vp, u64]
         L.nimble_call_counters.argtypes = [vp, C.POINTER(u64)]
         L.nimble_call_timing.argtypes = [vp, C.POINTER(C.c_float)]
+        L.nimble_key_words.argtypes = [u32, i32]
+        L.nimble_key_words.restype = u32
+        L.nimble_pack.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
+        L.nimble_call_packed.argtypes = [vp, C.POINTER(AlignParams), C.POINTER(NimblePacked), u64, u32]
         _hip = L
     return _hip
 
@@ -287,6 +300,7 @@ HOST_SYMBOLS = [
     "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
+    "nimble_library_pack", "nimble_score_call_packed",
 ]
 
 
@@ -336,6 +350,8 @@ def host_lib():
         L.nimble_library_ctx.restype = vp
         L.nimble_score_call.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(vp)]
         L.nimble_score_call_fastq.argtypes = [vp, cp, cp, C.POINTER(vp)]
+        L.nimble_library_pack.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
+        L.nimble_score_call_packed.argtypes = [vp, C.POINTER(NimblePacked), u64, u32, C.POINTER(vp)]
         L.nimble_rows_free.argtypes = [vp]
         L.nimble_rows_free.restype = None
         L.nimble_rows_count.argtypes = [vp]
@@ -384,6 +400,57 @@ def _rows(handle):
         return out
     finally:
         L.nimble_rows_free(handle)
+
+
+class PackedTensors:
+    """torch-owned device arrays of the packed form (mirror of nimble_packed)."""
+
+    def __init__(self, keys, len0, len1, hash_, pre0, pre1, max_len, paired):
+        self.keys, self.len0, self.len1, self.hash, self.pre0, self.pre1 = keys, len0, len1, hash_, pre0, pre1
+        self.max_len, self.paired = int(max_len), bool(paired)
+        self.key_words = int(keys.shape[0])
+        self.n = int(keys.shape[1])
+
+    @classmethod
+    def empty(cls, n, max_len, paired, device):
+        import torch
+        kw = int(hip_lib().nimble_key_words(max_len, int(paired)))
+        m = max(n, 1)
+        return cls(torch.zeros((kw, m), dtype=torch.int64, device=device)[:, :n],
+                   torch.zeros(m, dtype=torch.int32, device=device)[:n],
+                   torch.zeros(m, dtype=torch.int32, device=device)[:n],
+                   torch.zeros(m, dtype=torch.int64, device=device)[:n],
+                   torch.zeros(m, dtype=torch.uint8, device=device)[:n],
+                   torch.zeros(m, dtype=torch.uint8, device=device)[:n], max_len, paired)
+
+    def as_struct(self):
+        st = NimblePacked()
+        assert self.keys.is_contiguous() or self.n == 0
+        st.keys = self.keys.data_ptr()
+        st.len[0] = self.len0.data_ptr()
+        st.len[1] = self.len1.data_ptr() if self.paired else None
+        st.hash = self.hash.data_ptr()
+        st.pre[0] = self.pre0.data_ptr()
+        st.pre[1] = self.pre1.data_ptr() if self.paired else None
+        st.key_words = self.key_words
+        st.paired = int(self.paired)
+        return st
+
+    # one int64 record per read for the exchange: [key words..., hash, len0 | len1 << 16 | pre0 << 32 | pre1 << 40]
+    def to_records(self):
+        import torch
+        meta = (self.len0.to(torch.int64) | (self.len1.to(torch.int64) << 16) | (self.pre0.to(torch.int64) << 32)
+                | (self.pre1.to(torch.int64) << 40))
+        return torch.cat([self.keys.t(), self.hash[:, None], meta[:, None]], dim=1).contiguous()
+
+    @classmethod
+    def from_records(cls, rec, key_words, max_len, paired):
+        import torch
+        keys = rec[:, :key_words].t().contiguous()
+        meta = rec[:, key_words + 1]
+        return cls(keys, (meta & 0xFFFF).to(torch.int32), ((meta >> 16) & 0xFFFF).to(torch.int32),
+                   rec[:, key_words].contiguous(), ((meta >> 32) & 0xFF).to(torch.uint8),
+                   ((meta >> 40) & 0xFF).to(torch.uint8), max_len, paired)
 
 
 class RowsHandle:
@@ -505,6 +572,27 @@ class Library:
             b2, o2 = pack_reads(mates)
             return self.score_call(b1, o1, b2, o2)
         return self.score_call(b1, o1)
+
+    def pack(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST,
+             device="cuda:0"):
+        """First half of the split call: 2-bit packed keys, lengths, key hash and prefilter verdicts written into
+        torch tensors on `device` (a PackedTensors), ready to be exchanged between ranks."""
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        max_len = max(max_len or fixed_len, 1)
+        pt = PackedTensors.empty(n, max_len, r2 is not None, device)
+        st = pt.as_struct()
+        _hcheck(host_lib().nimble_library_pack(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+                                               max_len, mem, C.byref(st)))
+        return pt
+
+    def score_call_packed(self, pt, raw=False):
+        """Second half of the split call: score::call from packed arrays (possibly received from other ranks)."""
+        st = pt.as_struct()
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_call_packed(self.h, C.byref(st), pt.n, pt.max_len, C.byref(h)))
+        self._keep_packed = pt  # the arrays must outlive the asynchronous device call
+        return RowsHandle(h) if raw else _rows(h)
 
     def device_context(self):
         """The device context behind this library's PseudoAligner (stage timings, counters, records)."""

@@ -122,6 +122,7 @@ struct nimble_ctx {
   uint64_t dslots = 0;
   uint64_t dedup_clean_slots = 0;  // slots [0, this) of b_dedup are known to be zero (cleared at the tail of the last call)
   bool finished = true;
+  bool skip_pack = false;  // the call started from packed keys (nimble_call_packed)
   int attempt = 0;
   std::vector<uint64_t> h_state = std::vector<uint64_t>(16, 0);
   std::vector<uint32_t> h_c1, h_c2;  // histogram of the last finished call, sorted by (c1, c2)
@@ -225,10 +226,11 @@ int enqueue_call(nimble_ctx *c) {
   c->dedup_clean_slots = 0;
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
-  if (!cb.paired) HIPCHK(hipMemsetAsync(c->b_len[1].p, 0, nn * 4, s));
+  if (!cb.paired) HIPCHK(hipMemsetAsync(cb.len[1], 0, nn * 4, s));
   HIPCHK(hipEventRecord(c->ev[0], s));
-  launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
-              c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
+  if (!c->skip_pack)
+    launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
+                c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
   HIPCHK(hipEventRecord(c->ev[1], s));
   launch_align(s, c->ix->dev, c->prm, cb, c->want_counters);
   HIPCHK(hipEventRecord(c->ev[2], s));
@@ -567,9 +569,42 @@ int nimble_ctx_synchronize(nimble_ctx *c) {
   return NIMBLE_OK;
 }
 
-int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
-                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
-  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call: NULL argument");
+// stage the read buffers on the device when they are handed over as host memory
+static int stage_inputs(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                        const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  c->in_r[0] = r1;
+  c->in_r[1] = r2;
+  c->in_off[0] = r1_off;
+  c->in_off[1] = r2_off;
+  c->in_fixed_len = fixed_len;
+  c->in_max_len = max_len;
+  if (mem != NIMBLE_MEM_HOST) return NIMBLE_OK;
+  const int nm = r2 ? 2 : 1;
+  for (int m = 0; m < nm; ++m) {
+    const uint8_t *src = m ? r2 : r1;
+    const uint64_t *off = m ? r2_off : r1_off;
+    uint64_t bytes = off ? off[n] : n * (uint64_t)fixed_len;
+    if (off) {
+      for (uint64_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i] || off[i + 1] - off[i] > max_len)
+          return fail(NIMBLE_E_INVALID, "nimble_call: offsets not monotone or a read longer than max_len");
+    }
+    int rc = c->b_in[m].ensure(std::max<uint64_t>(bytes, 16), &c->bytes);
+    if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(c->b_in[m].p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    c->in_r[m] = c->b_in[m].as<uint8_t>();
+    if (off) {
+      rc = c->b_in_off[m].ensure((n + 1) * 8, &c->bytes);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(c->b_in_off[m].p, off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+      c->in_off[m] = c->b_in_off[m].as<uint64_t>();
+    }
+  }
+  return NIMBLE_OK;
+}
+
+static int check_read_args(const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2, const uint64_t *r2_off,
+                           uint64_t n, uint32_t fixed_len, uint32_t &max_len, int mem) {
   if (n && !r1) return fail(NIMBLE_E_INVALID, "nimble_call: r1 is NULL");
   if (!r1_off && fixed_len == 0 && n) return fail(NIMBLE_E_INVALID, "nimble_call: neither offsets nor fixed_len given");
   if (r2 && ((r1_off == nullptr) != (r2_off == nullptr)))
@@ -579,42 +614,18 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (max_len == 0) max_len = 1;
   if (max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call: max_len above 65535 is not supported");
   if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE) return fail(NIMBLE_E_INVALID, "nimble_call: bad mem");
-  nimble_index *ix = c->ix;
-  HIPCHK(hipSetDevice(ix->device));
-  hipStream_t s = c->stream;
-  const bool paired = r2 != nullptr;
+  return NIMBLE_OK;
+}
+
+// Buffers and tables of one call over n reads.  `ext` (may be NULL) supplies caller-owned device arrays for the
+// packed form (keys, lengths, key hash, prefilter verdicts) instead of the context's own.
+static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, bool paired, uint32_t max_len,
+                      const nimble_packed *ext) {
   const int nm = paired ? 2 : 1;
   const uint32_t kw = (max_len * (uint32_t)nm + 31u) / 32u;
-  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 > 64 * 1024)
-    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~960)");
-
-  // ---- inputs
-  const uint8_t *d_r[2] = {r1, r2};
-  const uint64_t *d_off[2] = {r1_off, r2_off};
-  if (mem == NIMBLE_MEM_HOST) {
-    for (int m = 0; m < nm; ++m) {
-      const uint8_t *src = m ? r2 : r1;
-      const uint64_t *off = m ? r2_off : r1_off;
-      uint64_t bytes = off ? off[n] : n * (uint64_t)fixed_len;
-      if (off) {
-        for (uint64_t i = 0; i < n; ++i)
-          if (off[i + 1] < off[i] || off[i + 1] - off[i] > max_len)
-            return fail(NIMBLE_E_INVALID, "nimble_call: offsets not monotone or a read longer than max_len");
-      }
-      int rc = c->b_in[m].ensure(std::max<uint64_t>(bytes, 16), &c->bytes);
-      if (rc) return rc;
-      if (bytes) HIPCHK(hipMemcpyAsync(c->b_in[m].p, src, bytes, hipMemcpyHostToDevice, s));
-      d_r[m] = c->b_in[m].as<uint8_t>();
-      if (off) {
-        rc = c->b_in_off[m].ensure((n + 1) * 8, &c->bytes);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->b_in_off[m].p, off, (n + 1) * 8, hipMemcpyHostToDevice, s));
-        d_off[m] = c->b_in_off[m].as<uint64_t>();
-      }
-    }
-  }
-
-  // ---- per-call buffers
+  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 > 64 * 1024)
+    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~900)");
+  if (ext && ext->key_words != kw) return fail(NIMBLE_E_INVALID, "packed buffers: key_words does not match max_len");
   CallBuffers &cb = c->cb;
   cb.n = n;
   cb.key_words = kw;
@@ -624,13 +635,17 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   auto need = [&](DevBuf &b, size_t bytes) {
     if (rc == NIMBLE_OK) rc = b.ensure(bytes, &c->bytes);
   };
-  need(c->b_keys, nn * kw * 8);
-  need(c->b_hash, nn * 8);
+  if (!ext) {
+    need(c->b_keys, nn * kw * 8);
+    need(c->b_hash, nn * 8);
+  }
   need(c->b_slot, nn * 4);
   need(c->b_counted, nn);
   for (int m = 0; m < 2; ++m) {
-    need(c->b_len[m], nn * 4);
-    need(c->b_pre[m], nn);
+    if (!ext || (m == 1 && !ext->len[1])) {
+      need(c->b_len[m], nn * 4);
+      need(c->b_pre[m], nn);
+    }
     need(c->b_reason[m], nn);
     need(c->b_score[m], nn * 4);
     need(c->b_mism[m], nn * 4);
@@ -662,13 +677,14 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   rc = ensure_min_cov(c, p->score_percent, max_len);
   if (rc != NIMBLE_OK) return rc;
 
-  cb.keys = c->b_keys.as<uint64_t>();
-  cb.key_hash = c->b_hash.as<uint64_t>();
+  cb.keys = ext ? ext->keys : c->b_keys.as<uint64_t>();
+  cb.key_hash = ext ? ext->hash : c->b_hash.as<uint64_t>();
   cb.slot = c->b_slot.as<uint32_t>();
   cb.counted = c->b_counted.as<uint8_t>();
   for (int m = 0; m < 2; ++m) {
-    cb.len[m] = c->b_len[m].as<uint32_t>();
-    cb.pre[m] = c->b_pre[m].as<uint8_t>();
+    const bool use_ext = ext && ext->len[m];
+    cb.len[m] = use_ext ? ext->len[m] : c->b_len[m].as<uint32_t>();
+    cb.pre[m] = use_ext ? ext->pre[m] : c->b_pre[m].as<uint8_t>();
     cb.reason[m] = c->b_reason[m].as<uint8_t>();
     cb.score[m] = c->b_score[m].as<uint32_t>();
     cb.mism[m] = c->b_mism[m].as<uint32_t>();
@@ -690,27 +706,72 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
   cb.hist_mask = c->hist_slots - 1;
   cb.state = c->b_state.as<uint64_t>();
-
-  uint32_t dst[4];
-  HIPCHK(hipMemcpyAsync(dst, ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  c->dyn_before = dst[0];
-
   c->prm = *p;
   if (c->prm.min_read_length == 0) c->prm.min_read_length = 40;
-  c->in_r[0] = d_r[0];
-  c->in_r[1] = d_r[1];
-  c->in_off[0] = d_off[0];
-  c->in_off[1] = d_off[1];
-  c->in_fixed_len = fixed_len;
-  c->in_max_len = max_len;
   c->dslots = dslots;
+  return NIMBLE_OK;
+}
+
+static int start_call(nimble_ctx *c) {
+  uint32_t dst[4];
+  HIPCHK(hipMemcpyAsync(dst, c->ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->dyn_before = dst[0];
   c->finished = false;
   c->attempt = 0;
-  rc = enqueue_call(c);
+  int rc = enqueue_call(c);
   if (rc) return rc;
   c->called = true;
   return NIMBLE_OK;
+}
+
+int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
+                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call: NULL argument");
+  int rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->ix->device));
+  rc = stage_inputs(c, r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  rc = setup_call(c, p, n, r2 != nullptr, max_len, nullptr);
+  if (rc) return rc;
+  c->skip_pack = false;
+  return start_call(c);
+}
+
+uint32_t nimble_key_words(uint32_t max_len, int paired) { return (max_len * (paired ? 2u : 1u) + 31u) / 32u; }
+
+int nimble_pack(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
+                const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                const nimble_packed *out) {
+  if (!c || !p || !out) return fail(NIMBLE_E_INVALID, "nimble_pack: NULL argument");
+  if (!out->keys || !out->hash || !out->len[0] || !out->pre[0] || (r2 && (!out->len[1] || !out->pre[1])))
+    return fail(NIMBLE_E_INVALID, "nimble_pack: output arrays missing");
+  int rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->ix->device));
+  rc = stage_inputs(c, r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  rc = setup_call(c, p, n, r2 != nullptr, max_len, out);
+  if (rc) return rc;
+  launch_pack(c->stream, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
+              c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, c->cb);
+  HIPCHK(hipGetLastError());
+  return NIMBLE_OK;
+}
+
+int nimble_call_packed(nimble_ctx *c, const nimble_align_params *p, const nimble_packed *in, uint64_t n,
+                       uint32_t max_len) {
+  if (!c || !p || !in) return fail(NIMBLE_E_INVALID, "nimble_call_packed: NULL argument");
+  if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0]))
+    return fail(NIMBLE_E_INVALID, "nimble_call_packed: packed arrays missing");
+  if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_call_packed: more than 2^32 reads in one call");
+  if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call_packed: bad max_len");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = setup_call(c, p, n, in->paired != 0, max_len, in);
+  if (rc) return rc;
+  c->skip_pack = true;
+  return start_call(c);
 }
 
 static int finish_count_stage(nimble_ctx *c) { return finish_call(c); }

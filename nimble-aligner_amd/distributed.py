@@ -5,9 +5,10 @@ Reads are independent except for the dedup-by-sequence of `score_map` (src/align
 key must be counted once per call, so all copies of a key have to meet on one rank.  The path therefore
 has one real exchange step and one reduction:
 
-  1. partition : dest = hash(read key) mod world                     (per rank, on device)
-  2. exchange  : all_to_all of the reads, bucketed by dest            (RCCL all-to-all)
-  3. compute   : score::call on the received shard                    (HIP path, no collective)
+  0. pack      : ASCII -> 2-bit keys + canonical key hash, where the reads are   (nimble_pack)
+  1. partition : dest = key hash mod world                            (per rank, on device)
+  2. exchange  : all_to_all of the PACKED records, bucketed by dest   (RCCL all-to-all, 56 B/read)
+  3. compute   : rest of score::call on the received shard            (nimble_call_packed, no collective)
   4. reduce    : per-callset counts summed over ranks                 (RCCL all-reduce of a dense
                                                                        int64 vector over the union of
                                                                        callsets; tiny, latency-bound)
@@ -26,12 +27,21 @@ def _weights(width, device):
     return w.to(device)
 
 
+def _canonical(r):
+    """Bases as the read key sees them (DnaString::from_acgt_bytes + to_string): upper-case A/C/G/T, anything
+    else reads as 'A'.  The partition must be a function of the KEY, not of the raw bytes."""
+    x = r & 0xDF
+    ok = (x == 65) | (x == 67) | (x == 71) | (x == 84)
+    return torch.where(ok, x, torch.full_like(x, 65))
+
+
 def key_partition(r1, r2, world):
-    """dest rank per read(-pair): a function of the base content only, so equal keys share a rank.
-    r1/r2: uint8 tensors [n, L] (r2 may be None)."""
-    h = (r1.to(torch.int64) * _weights(r1.shape[1], r1.device)).sum(dim=1)
+    """dest rank per read(-pair): a function of the read key only, so equal keys share a rank.
+    r1/r2: uint8 tensors [n, L] (r2 may be None).  Generic ASCII form (CPU rehearsal); the GPU path routes
+    on the key hash computed by the pack kernel (sharded_call_packed)."""
+    h = (_canonical(r1).to(torch.int64) * _weights(r1.shape[1], r1.device)).sum(dim=1)
     if r2 is not None:
-        h = h * 1000003 + (r2.to(torch.int64) * _weights(r2.shape[1], r2.device)).sum(dim=1)
+        h = h * 1000003 + (_canonical(r2).to(torch.int64) * _weights(r2.shape[1], r2.device)).sum(dim=1)
     h = h ^ (h >> 29)
     h = h * 0x2545F4914F6CDD1D  # wraps in int64; only equality of equal keys matters
     h = h ^ (h >> 32)
@@ -58,6 +68,25 @@ def exchange_reads(r1, r2, dest, group=None):
     return out[0], out[1]
 
 
+def exchange_records(rec, dest, group=None):
+    """all_to_all of fixed-width records (2-D tensor, one row per read) by destination rank."""
+    world = dist.get_world_size(group)
+    order = torch.argsort(dest.to(torch.uint8) if world <= 256 else dest, stable=True)  # one radix pass
+    counts = torch.bincount(dest, minlength=world)
+    recv = torch.empty_like(counts)
+    dist.all_to_all_single(recv, counts, group=group)
+    in_split, out_split = counts.tolist(), recv.tolist()
+    send = rec[order].contiguous()
+    got = torch.empty((sum(out_split), rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_to_all_single(got, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    return got
+
+
+def hash_partition(key_hash, world):
+    """dest rank from the 64-bit key hash of the pack kernel (stored in an int64 tensor)."""
+    return torch.remainder(key_hash & 0x7FFFFFFFFFFFFFFF, world)
+
+
 def reduce_tables(rows, device, group=None):
     """Sum per-callset counts over ranks.  rows: [(features list, count)].  Every rank gets the merged
     table sorted by callset (the order of utils::sort_score_vector, src/utils.rs:54-59)."""
@@ -75,6 +104,26 @@ def reduce_tables(rows, device, group=None):
     dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     counts = vec.tolist()
     return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
+
+
+def sharded_call_packed(lib, r1, r2, n, fixed_len, device, group=None, raw=False):
+    """The multi-GPU step on the HIP path: pack locally (2 bits per base, canonical key hash), exchange the
+    packed records by key hash (40-56 B per read instead of 150-300 B of ASCII), finish score::call on the
+    receiving rank, all-reduce the counts.  r1/r2: uint8 device tensors [n, fixed_len]."""
+    nim = __import__("importlib").import_module("nimble-aligner_amd")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    pt = lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=nim.MEM_DEVICE,
+                  device=str(device))
+    if world > 1:
+        lib.device_context().synchronize()  # pack ran on the library's stream; torch reads its output next
+        rec = pt.to_records()
+        got = exchange_records(rec, hash_partition(pt.hash, world), group)
+        pt = nim.PackedTensors.from_records(got, pt.key_words, pt.max_len, pt.paired)
+        torch.cuda.current_stream().synchronize()
+    rows = lib.score_call_packed(pt, raw=raw and world == 1)
+    if world > 1:
+        rows = reduce_tables(rows, device, group)
+    return rows
 
 
 def sharded_call(compute, r1, r2, device, group=None):

@@ -353,14 +353,7 @@ const std::vector<uint32_t> &PseudoAligner::eq_class(uint32_t id) {
   return class_cache_.emplace(id, std::move(v)).first->second;
 }
 
-CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
-                     const reference_library::Reference &reference, const AlignFilterConfig &config,
-                     bool want_per_read) {
-  if (mates && mates->n != seqs.n)
-    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
-  static const bool timing = getenv("NIMBLE_HOST_TIMING") != nullptr;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto t0 = now();
+static nimble_align_params make_params(const AlignFilterConfig &config) {
   nimble_align_params p;
   memset(&p, 0, sizeof p);
   p.score_percent = config.score_percent;
@@ -370,6 +363,41 @@ CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligne
   p.discard_multiple_matches = config.discard_multiple_matches;
   p.require_valid_pair = config.require_valid_pair;
   p.min_read_length = (uint32_t)MIN_READ_LENGTH;
+  return p;
+}
+
+static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
+                               const AlignFilterConfig &config, bool want_per_read,
+                               std::chrono::steady_clock::time_point t0);
+
+void pack_reads(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index, const AlignFilterConfig &config,
+                const nimble_packed &out) {
+  if (mates && mates->n != seqs.n)
+    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  nimble_align_params p = make_params(config);
+  uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
+  if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
+  check_rc(nimble_pack(index.ctx(), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+                       mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
+                       seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST, &out),
+           "nimble_pack");
+}
+
+CallOutput get_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
+                            const reference_library::Reference &reference, const AlignFilterConfig &config) {
+  auto t0 = std::chrono::steady_clock::now();
+  nimble_align_params p = make_params(config);
+  check_rc(nimble_call_packed(index.ctx(), &p, &in, n, max_len), "nimble_call_packed");
+  return finish_calls(n, index, reference, config, false, t0);
+}
+
+CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
+                     const reference_library::Reference &reference, const AlignFilterConfig &config,
+                     bool want_per_read) {
+  if (mates && mates->n != seqs.n)
+    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  auto t0 = std::chrono::steady_clock::now();
+  nimble_align_params p = make_params(config);
   uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
   if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
   // the device call is asynchronous: the coercion tables are (re)built while the GPU works
@@ -377,6 +405,14 @@ CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligne
                        mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
                        seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
            "nimble_call");
+  return finish_calls(seqs.n, index, reference, config, want_per_read, t0);
+}
+
+static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
+                               const AlignFilterConfig &config, bool want_per_read,
+                               std::chrono::steady_clock::time_point t0) {
+  static const bool timing = getenv("NIMBLE_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
   PseudoAligner::CoercionMemo &memo = index.memo_for(reference, config);
   auto t1 = now();
   uint64_t ne = 0;
@@ -427,15 +463,15 @@ CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligne
             ms(t0, t1), ms(t1, t2), (unsigned long long)ne, ms(t2, t3), ms(t3, t4));
   }
   if (want_per_read) {
-    out.per_read.resize(seqs.n);
+    out.per_read.resize(n_reads);
     std::vector<int32_t> r[2], s[2];
     for (int m = 0; m < 2; ++m) {
-      r[m].resize(seqs.n);
-      s[m].resize(seqs.n);
-      check_rc(nimble_read_records(index.ctx(), m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, seqs.n),
+      r[m].resize(n_reads);
+      s[m].resize(n_reads);
+      check_rc(nimble_read_records(index.ctx(), m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, n_reads),
                "nimble_read_records");
     }
-    for (uint64_t i = 0; i < seqs.n; ++i) {
+    for (uint64_t i = 0; i < n_reads; ++i) {
       FilterRecord &fr = out.per_read[i];
       fr.r1 = (FilterReason)r[0][i];
       fr.r2 = (FilterReason)r[1][i];
@@ -500,6 +536,15 @@ align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch
   align::CallOutput out = align::get_calls(sequences, mate_sequences, reference_index, reference, aligner_config,
                                            want_per_read);
   // utils::sort_score_vector (utils.rs:54-59): Vec<String> ordering, byte-wise per string
+  std::sort(out.rows.begin(), out.rows.end(),
+            [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+  return out;
+}
+
+align::CallOutput call_packed(const nimble_packed &in, uint64_t n, uint32_t max_len,
+                              align::PseudoAligner &reference_index, const reference_library::Reference &reference,
+                              const align::AlignFilterConfig &aligner_config) {
+  align::CallOutput out = align::get_calls_packed(in, n, max_len, reference_index, reference, aligner_config);
   std::sort(out.rows.begin(), out.rows.end(),
             [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
   return out;

@@ -159,6 +159,34 @@ int nimble_score_call(nimble_library *l, const uint8_t *r1, const uint64_t *r1_o
   });
 }
 
+int nimble_library_pack(nimble_library *l, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                        const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                        const nimble_packed *out) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_library_pack: the library has no index");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    align::pack_reads(b1, r2 ? &b2 : nullptr, *l->index, l->cfg, *out);
+  });
+}
+
+int nimble_score_call_packed(nimble_library *l, const nimble_packed *in, uint64_t n, uint32_t max_len,
+                             nimble_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_packed: the library has no index");
+    *out = make_rows(score::call_packed(*in, n, max_len, *l->index, l->ref, l->cfg));
+  });
+}
+
 int nimble_score_call_fastq(nimble_library *l, const char *p1, const char *p2, nimble_rows **out) {
   *out = nullptr;
   return guarded([&] {

@@ -22,6 +22,7 @@
 
 struct nimble_index;
 struct nimble_ctx;
+struct nimble_packed;
 
 namespace nimble {
 
@@ -168,6 +169,13 @@ CallOutput get_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences
                      const reference_library::Reference &reference, const AlignFilterConfig &config,
                      bool want_per_read = false);
 
+// Split form used by the multi-GPU driver: pack where the reads are, exchange the packed form, run the rest
+// of get_calls on the receiving rank (include/nimble_hip.h: nimble_pack / nimble_call_packed).
+void pack_reads(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
+                const AlignFilterConfig &config, const nimble_packed &out);
+CallOutput get_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
+                            const reference_library::Reference &reference, const AlignFilterConfig &config);
+
 // The coercion of one (class R1, class R2) pair into a callset: filter_and_coerce_sequence_call_orientations
 // (src/align.rs:178-252).  Pure host code; evaluated once per distinct pair of a call.
 class Coercer {
@@ -192,6 +200,9 @@ namespace score {
 align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch *mate_sequences,
                        align::PseudoAligner &reference_index, const reference_library::Reference &reference,
                        const align::AlignFilterConfig &aligner_config, bool want_per_read = false);
+align::CallOutput call_packed(const nimble_packed &in, uint64_t n, uint32_t max_len,
+                              align::PseudoAligner &reference_index, const reference_library::Reference &reference,
+                              const align::AlignFilterConfig &aligner_config);
 }  // namespace score
 
 namespace parse {

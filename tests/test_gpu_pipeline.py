@@ -161,3 +161,39 @@ def test_mismatched_pair_files_panic(synth_lib, tmp_path):
         lib.score_call_fastq(f1, f2)
     with pytest.raises(nim.Panic, match="Input R1 data malformed"):
         lib.score_call_fastq(os.path.join(GOLDEN, "reads", "fastq_invalid_data.fastq"))
+
+
+def test_split_call_pack_then_call_packed_equals_direct_call(synth_lib):
+    # the split form used between ranks: pack -> (records round trip) -> call_packed == direct call
+    torch = pytest.importorskip("torch")
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    for paired in (False, True):
+        if paired:
+            r1, r2 = synth.make_reads(seqs, 30000, paired=True, seed=77)
+        else:
+            r1, r2 = synth.make_reads(seqs, 30000, seed=78), None
+        n = r1.shape[0]
+        o = synth.fixed_offsets(n, 150)
+        direct = lib.score_call(r1.reshape(-1), o, None if r2 is None else r2.reshape(-1), None if r2 is None else o)
+        d1 = torch.from_numpy(r1.copy()).to("cuda:0")
+        d2 = None if r2 is None else torch.from_numpy(r2.copy()).to("cuda:0")
+        torch.cuda.synchronize()
+        pt = lib.pack(d1, None, d2, None, n=n, fixed_len=150, max_len=150, mem=nim.MEM_DEVICE)
+        lib.device_context().synchronize()
+        assert lib.score_call_packed(pt) == direct
+        # records round trip (what the all-to-all carries)
+        pt2 = nim.PackedTensors.from_records(pt.to_records(), pt.key_words, pt.max_len, pt.paired)
+        torch.cuda.synchronize()
+        assert lib.score_call_packed(pt2) == direct
+        # two "ranks" on one GPU: route by key hash, finish each shard separately, counts add up exactly
+        nd = importlib.import_module("nimble-aligner_amd.distributed")
+        dest = nd.hash_partition(pt.hash, 2)
+        rec = pt.to_records()
+        merged = {}
+        for rank in (0, 1):
+            shard = nim.PackedTensors.from_records(rec[dest == rank].contiguous(), pt.key_words, pt.max_len, pt.paired)
+            torch.cuda.synchronize()
+            for f, c in lib.score_call_packed(shard):
+                merged[tuple(f)] = merged.get(tuple(f), 0) + c
+        assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
