@@ -93,6 +93,10 @@ int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32
 /* stream: a hipStream_t (as void*) to launch on, or NULL for the context's own stream. */
 int nimble_ctx_create(nimble_index *, void *stream, nimble_ctx **out);
 void nimble_ctx_free(nimble_ctx *);
+/* The hipStream_t the context launches on.  A second context created on the same stream keeps two calls in
+ * flight back to back: call i+1 runs on the GPU while the host reads the histogram of call i (results are
+ * fetched on a side stream that waits only for their own call). */
+void *nimble_ctx_stream(nimble_ctx *);
 
 /* Options: NIMBLE_OPT_COUNTERS (default 1) -- collect the work counters of nimble_call_counters inside the
  * align kernel; switch off for timed runs. */

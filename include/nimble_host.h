@@ -62,11 +62,19 @@ int nimble_library_build_index(nimble_library *, int device);
 /* the device handles behind the library's PseudoAligner (NULL before build_index); borrowed */
 void *nimble_library_index(nimble_library *);
 void *nimble_library_ctx(nimble_library *);
+void *nimble_library_ctx_slot(nimble_library *, int slot); /* context of a begin/end slot (0 or 1); NULL on error */
 
 /* score::call.  r2 == NULL for single-end; *_off == NULL means fixed_len; mem as in nimble_hip.h */
 int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                       const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                       nimble_rows **out);
+/* score::call in two halves, for callers that stream batches (the BAM pipeline calls score::call once per UMI
+ * batch, src/process/bam.rs:183-226): begin enqueues the device work of one batch and returns; end waits for that
+ * slot and returns its sorted rows.  Two slots (0, 1) share one launch stream, so batch i+1 runs on the GPU while
+ * the host turns batch i's histogram into rows.  The read buffers of a slot are borrowed until its end. */
+int nimble_score_call_begin(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                            const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem);
+int nimble_score_call_end(nimble_library *, int slot, nimble_rows **out);
 /* split form of score::call for the multi-GPU driver (see nimble_pack / nimble_call_packed in nimble_hip.h):
  * pack on the rank that holds the reads, exchange the packed arrays, finish on the receiving rank */
 int nimble_library_pack(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,

@@ -73,7 +73,7 @@ HIP_SYMBOLS = [
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
-    "nimble_call_packed",
+    "nimble_call_packed", "nimble_ctx_stream",
 ]
 
 
@@ -110,6 +110,8 @@ def hip_lib():
         L.nimble_key_words.restype = u32
         L.nimble_pack.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
         L.nimble_call_packed.argtypes = [vp, C.POINTER(AlignParams), C.POINTER(NimblePacked), u64, u32]
+        L.nimble_ctx_stream.argtypes = [vp]
+        L.nimble_ctx_stream.restype = vp
         _hip = L
     return _hip
 
@@ -300,7 +302,8 @@ HOST_SYMBOLS = [
     "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
-    "nimble_library_pack", "nimble_score_call_packed",
+    "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
+    "nimble_library_ctx_slot",
 ]
 
 
@@ -350,6 +353,10 @@ def host_lib():
         L.nimble_library_ctx.restype = vp
         L.nimble_score_call.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(vp)]
         L.nimble_score_call_fastq.argtypes = [vp, cp, cp, C.POINTER(vp)]
+        L.nimble_score_call_begin.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, u32, i32]
+        L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
+        L.nimble_library_ctx_slot.argtypes = [vp, i32]
+        L.nimble_library_ctx_slot.restype = vp
         L.nimble_library_pack.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
         L.nimble_score_call_packed.argtypes = [vp, C.POINTER(NimblePacked), u64, u32, C.POINTER(vp)]
         L.nimble_rows_free.argtypes = [vp]
@@ -566,6 +573,25 @@ class Library:
                                              max(max_len or fixed_len, 1), mem, C.byref(h)))
         return RowsHandle(h)
 
+    def score_call_begin(self, slot, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0,
+                         mem=MEM_HOST):
+        """First half of score::call for streamed batches: enqueue the device work of one batch in `slot` (0/1)
+        and return.  The buffers must stay alive until score_call_end(slot)."""
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        if max_len == 0 and r1_off is not None and isinstance(r1_off, np.ndarray) and n:
+            max_len = int(np.diff(r1_off.astype(np.int64)).max())
+            if r2_off is not None:
+                max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()))
+        _hcheck(host_lib().nimble_score_call_begin(self.h, slot, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+                                                   fixed_len, max(max_len or fixed_len, 1), mem))
+
+    def score_call_end(self, slot, raw=False):
+        """Second half: wait for the slot's batch, return its sorted rows (a RowsHandle when raw)."""
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_call_end(self.h, slot, C.byref(h)))
+        return RowsHandle(h) if raw else _rows(h)
+
     def score_call_reads(self, reads, mates=None):
         b1, o1 = pack_reads(reads)
         if mates is not None:
@@ -594,9 +620,9 @@ class Library:
         self._keep_packed = pt  # the arrays must outlive the asynchronous device call
         return RowsHandle(h) if raw else _rows(h)
 
-    def device_context(self):
+    def device_context(self, slot=0):
         """The device context behind this library's PseudoAligner (stage timings, counters, records)."""
-        p = host_lib().nimble_library_ctx(self.h)
+        p = host_lib().nimble_library_ctx_slot(self.h, slot)
         if not p:
             raise Panic("the library has no index")
         return Context(borrowed=p)

@@ -96,6 +96,11 @@ struct nimble_ctx {
   nimble_index *ix = nullptr;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // Results come back on a side stream that waits for the call's last event: when two contexts share one
+  // launch stream (calls in flight back to back), reading one call's results does not wait for the next call.
+  hipStream_t copy_stream = nullptr;
+  uint64_t *p_state = nullptr;  // pinned mirrors of b_state / the index's dyn_state at call start
+  uint32_t *p_dyn = nullptr;
   CallBuffers cb{};
   uint64_t bytes = 0;
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
@@ -138,6 +143,9 @@ struct nimble_ctx {
     if (have_events)
       for (auto &e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (p_state) (void)hipHostFree(p_state);
+    if (p_dyn) (void)hipHostFree(p_dyn);
   }
 };
 
@@ -197,9 +205,17 @@ int ensure_min_cov(nimble_ctx *c, double percent, uint32_t max_len) {
   return NIMBLE_OK;
 }
 
+// ev[6] marks the end of everything enqueued for the call so far
+int mark_done(nimble_ctx *c) {
+  HIPCHK(hipEventRecord(c->ev[6], c->stream));
+  return NIMBLE_OK;
+}
+
 int fetch_state(nimble_ctx *c) {
-  HIPCHK(hipMemcpyAsync(c->h_state.data(), c->b_state.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev[6], 0));
+  HIPCHK(hipMemcpyAsync(c->p_state, c->b_state.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+  HIPCHK(hipStreamSynchronize(c->copy_stream));
+  std::copy(c->p_state, c->p_state + 16, c->h_state.begin());
   return NIMBLE_OK;
 }
 
@@ -246,7 +262,7 @@ int enqueue_call(nimble_ctx *c) {
   int rc = enqueue_compact(c);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  return NIMBLE_OK;
+  return mark_done(c);
 }
 
 int redo_dedup_count(nimble_ctx *c) {
@@ -260,7 +276,8 @@ int redo_dedup_count(nimble_ctx *c) {
   HIPCHK(hipEventRecord(c->ev[4], s));
   launch_count(s, c->cb);
   HIPCHK(hipEventRecord(c->ev[5], s));
-  return enqueue_compact(c);
+  int rc = enqueue_compact(c);
+  return rc ? rc : mark_done(c);
 }
 
 // Wait for the call and resolve the rare conditions that need host intervention (pool growth, intern tag
@@ -292,7 +309,8 @@ int finish_call(nimble_ctx *c) {
         HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 9, 0, 8, c->stream));
         launch_intern_claim(c->stream, c->ix->dev, c->cb, round);
         launch_intern_verify(c->stream, c->ix->dev, c->cb);
-        rc = fetch_state(c);
+        rc = mark_done(c);
+        if (!rc) rc = fetch_state(c);
         if (rc) return rc;
         if (c->h_state[10] & (ERR_CLASS_CAP | ERR_IDS_CAP))
           return fail(NIMBLE_E_OVERFLOW, "dynamic class table full (raise NIMBLE_DYN_CLASSES / NIMBLE_DYN_IDS)");
@@ -326,10 +344,10 @@ int finish_call(nimble_ctx *c) {
     if (ne) {
       std::vector<uint32_t> a(ne), b(ne);
       std::vector<uint64_t> k(ne);
-      HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipStreamSynchronize(c->copy_stream));
       std::vector<uint64_t> order(ne);
       for (uint64_t i = 0; i < ne; ++i) order[i] = ((uint64_t)a[i] << 32) | b[i];
       std::vector<uint32_t> idx(ne);
@@ -344,6 +362,7 @@ int finish_call(nimble_ctx *c) {
     HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, c->stream));
     c->dedup_clean_slots = c->dslots;
   }
+  c->dyn_before = c->p_dyn[0];  // copied at the head of the call, ahead of everything fetch_state waited for
   c->finished = true;
   return NIMBLE_OK;
 }
@@ -541,6 +560,12 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
     }
   }
   c->have_events = true;
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void **)&c->p_state, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void **)&c->p_dyn, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return fail(NIMBLE_E_HIP, "nimble_ctx_create: side stream / pinned buffers");
+  }
   c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 1);
   *out = c;
   return NIMBLE_OK;
@@ -552,6 +577,8 @@ void nimble_ctx_free(nimble_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   delete c;
 }
+
+void *nimble_ctx_stream(nimble_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int nimble_ctx_set_option(nimble_ctx *c, int option, int64_t value) {
   if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
@@ -713,10 +740,8 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
 }
 
 static int start_call(nimble_ctx *c) {
-  uint32_t dst[4];
-  HIPCHK(hipMemcpyAsync(dst, c->ix->b_dyn_state.p, sizeof(dst), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->dyn_before = dst[0];
+  // number of interned classes before this call (for the counters); read back without waiting
+  HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->finished = false;
   c->attempt = 0;
   int rc = enqueue_call(c);

@@ -338,7 +338,15 @@ PseudoAligner::CoercionMemo &PseudoAligner::memo_for(const reference_library::Re
   return *memo_;
 }
 
+nimble_ctx *PseudoAligner::ctx(int slot) {
+  if (slot == 0) return ctx_;
+  if (slot != 1) throw Panic("PseudoAligner::ctx: slot must be 0 or 1");
+  if (!ctx2_) check_rc(nimble_ctx_create(index_, nimble_ctx_stream(ctx_), &ctx2_), "nimble_ctx_create");
+  return ctx2_;
+}
+
 PseudoAligner::~PseudoAligner() {
+  if (ctx2_) nimble_ctx_free(ctx2_);
   if (ctx_) nimble_ctx_free(ctx_);
   if (index_) nimble_index_free(index_);
 }
@@ -368,7 +376,7 @@ static nimble_align_params make_params(const AlignFilterConfig &config) {
 
 static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                                const AlignFilterConfig &config, bool want_per_read,
-                               std::chrono::steady_clock::time_point t0);
+                               std::chrono::steady_clock::time_point t0, int slot = 0);
 
 void pack_reads(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index, const AlignFilterConfig &config,
                 const nimble_packed &out) {
@@ -391,35 +399,46 @@ CallOutput get_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_le
   return finish_calls(n, index, reference, config, false, t0);
 }
 
-CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
-                     const reference_library::Reference &reference, const AlignFilterConfig &config,
-                     bool want_per_read) {
+void begin_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index, const AlignFilterConfig &config,
+                 int slot) {
   if (mates && mates->n != seqs.n)
     throw Panic("Error -- read and reverse read files do not have matching lengths: ");
-  auto t0 = std::chrono::steady_clock::now();
   nimble_align_params p = make_params(config);
   uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
   if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
   // the device call is asynchronous: the coercion tables are (re)built while the GPU works
-  check_rc(nimble_call(index.ctx(), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+  check_rc(nimble_call(index.ctx(slot), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                        mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
                        seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
            "nimble_call");
+}
+
+CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
+                     const AlignFilterConfig &config, int slot, bool want_per_read) {
+  return finish_calls(n_reads, index, reference, config, want_per_read, std::chrono::steady_clock::now(), slot);
+}
+
+CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
+                     const reference_library::Reference &reference, const AlignFilterConfig &config,
+                     bool want_per_read) {
+  auto t0 = std::chrono::steady_clock::now();
+  begin_calls(seqs, mates, index, config, 0);
   return finish_calls(seqs.n, index, reference, config, want_per_read, t0);
 }
 
 static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                                const AlignFilterConfig &config, bool want_per_read,
-                               std::chrono::steady_clock::time_point t0) {
+                               std::chrono::steady_clock::time_point t0, int slot) {
+  nimble_ctx *const ctx = index.ctx(slot);
   static const bool timing = getenv("NIMBLE_HOST_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   PseudoAligner::CoercionMemo &memo = index.memo_for(reference, config);
   auto t1 = now();
   uint64_t ne = 0;
-  check_rc(nimble_histogram(index.ctx(), nullptr, nullptr, nullptr, 0, &ne), "nimble_histogram");
+  check_rc(nimble_histogram(ctx, nullptr, nullptr, nullptr, 0, &ne), "nimble_histogram");
   std::vector<uint32_t> c1(ne), c2(ne);
   std::vector<uint64_t> cnt(ne);
-  if (ne) check_rc(nimble_histogram(index.ctx(), c1.data(), c2.data(), cnt.data(), ne, &ne), "nimble_histogram");
+  if (ne) check_rc(nimble_histogram(ctx, c1.data(), c2.data(), cnt.data(), ne, &ne), "nimble_histogram");
 
   auto t2 = now();
   // the `results` HashMap of align.rs:434, as dense counts over the memoised callsets
@@ -468,7 +487,7 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
     for (int m = 0; m < 2; ++m) {
       r[m].resize(n_reads);
       s[m].resize(n_reads);
-      check_rc(nimble_read_records(index.ctx(), m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, n_reads),
+      check_rc(nimble_read_records(ctx, m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, n_reads),
                "nimble_read_records");
     }
     for (uint64_t i = 0; i < n_reads; ++i) {

@@ -1,4 +1,5 @@
 // host_capi.cpp -- C ABI of the host mirror (include/nimble_host.h).
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/nimble_hip.h"
@@ -35,6 +36,8 @@ struct nimble_library {
   align::AlignFilterConfig cfg;
   reference_library::Reference ref;
   std::unique_ptr<align::PseudoAligner> index;
+  bool pending[2] = {false, false};  // nimble_score_call_begin without its _end yet
+  uint64_t pending_n[2] = {0, 0};
 };
 struct nimble_rows {
   std::vector<align::ScoreRow> rows;
@@ -131,6 +134,11 @@ int nimble_library_build_index(nimble_library *l, int device) {
 }
 void *nimble_library_index(nimble_library *l) { return l->index ? (void *)l->index->index() : nullptr; }
 void *nimble_library_ctx(nimble_library *l) { return l->index ? (void *)l->index->ctx() : nullptr; }
+void *nimble_library_ctx_slot(nimble_library *l, int slot) {
+  void *p = nullptr;
+  if (l->index && slot >= 0 && slot <= 1) guarded([&] { p = (void *)l->index->ctx(slot); });
+  return p;
+}
 
 static nimble_rows *make_rows(align::CallOutput &&o) {
   nimble_rows *r = new nimble_rows();
@@ -156,6 +164,41 @@ int nimble_score_call(nimble_library *l, const uint8_t *r1, const uint64_t *r1_o
     b2.bases = r2;
     b2.offsets = r2_off;
     *out = make_rows(score::call(b1, r2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
+  });
+}
+
+int nimble_score_call_begin(nimble_library *l, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                            const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_begin: the library has no index");
+    if (slot < 0 || slot > 1) throw Panic("nimble_score_call_begin: slot must be 0 or 1");
+    if (l->pending[slot]) throw Panic("nimble_score_call_begin: the slot already holds a call (end it first)");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    align::begin_calls(b1, r2 ? &b2 : nullptr, *l->index, l->cfg, slot);
+    l->pending[slot] = true;
+    l->pending_n[slot] = n;
+  });
+}
+
+int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_end: the library has no index");
+    if (slot < 0 || slot > 1 || !l->pending[slot]) throw Panic("nimble_score_call_end: no call was begun in this slot");
+    l->pending[slot] = false;
+    align::CallOutput o = align::end_calls(l->pending_n[slot], *l->index, l->ref, l->cfg, slot);
+    std::sort(o.rows.begin(), o.rows.end(),
+              [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+    *out = make_rows(std::move(o));
   });
 }
 

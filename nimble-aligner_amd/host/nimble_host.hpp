@@ -121,7 +121,9 @@ class PseudoAligner {
                                                     const std::vector<std::string> &names, int device = 0);
   ~PseudoAligner();
   nimble_index *index() const { return index_; }
-  nimble_ctx *ctx() const { return ctx_; }
+  // slot 0 is the context every call uses; slot 1 (created on first use, same launch stream) lets a second
+  // call be enqueued while the first one's results are read (begin_calls / end_calls)
+  nimble_ctx *ctx(int slot = 0);
   const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
 
   // Coercion memo: class ids are stable for the life of the index, and the coercion of a class pair depends
@@ -134,6 +136,7 @@ class PseudoAligner {
   PseudoAligner() = default;
   nimble_index *index_ = nullptr;
   nimble_ctx *ctx_ = nullptr;
+  nimble_ctx *ctx2_ = nullptr;
   std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
   std::shared_ptr<CoercionMemo> memo_;
 };
@@ -168,6 +171,13 @@ struct CallOutput {
 CallOutput get_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
                      const reference_library::Reference &reference, const AlignFilterConfig &config,
                      bool want_per_read = false);
+
+// get_calls in two halves, for callers that keep two calls in flight (batch i+1 on the GPU while the host
+// turns batch i's histogram into rows).  begin enqueues the device work and returns; end waits for that slot.
+void begin_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
+                 const AlignFilterConfig &config, int slot);
+CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
+                     const AlignFilterConfig &config, int slot, bool want_per_read = false);
 
 // Split form used by the multi-GPU driver: pack where the reads are, exchange the packed form, run the rest
 // of get_calls on the receiving rank (include/nimble_hip.h: nimble_pack / nimble_call_packed).

@@ -197,3 +197,34 @@ def test_split_call_pack_then_call_packed_equals_direct_call(synth_lib):
             for f, c in lib.score_call_packed(shard):
                 merged[tuple(f)] = merged.get(tuple(f), 0) + c
         assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
+
+
+def test_two_calls_in_flight_match_serial_calls(synth_lib):
+    # streamed batches (begin/end slots on one launch stream): results of each batch equal its own serial call,
+    # whatever the interleaving of begin and end
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    batches = [synth.make_reads(seqs, 20000 + 5000 * i, seed=200 + i) for i in range(5)]
+    serial = [lib.score_call(b.reshape(-1), None, n=b.shape[0], fixed_len=150) for b in batches]
+    flat = [np.ascontiguousarray(b.reshape(-1)) for b in batches]
+    got = [None] * len(batches)
+    for i, b in enumerate(batches):
+        lib.score_call_begin(i % 2, flat[i], None, n=b.shape[0], fixed_len=150)
+        if i:
+            got[i - 1] = lib.score_call_end((i - 1) % 2)
+    got[-1] = lib.score_call_end((len(batches) - 1) % 2)
+    assert got == serial
+    with pytest.raises(nim.Panic, match="no call was begun"):
+        lib.score_call_end(0)
+    lib.score_call_begin(0, flat[0], None, n=batches[0].shape[0], fixed_len=150)
+    with pytest.raises(nim.Panic, match="already holds a call"):
+        lib.score_call_begin(0, flat[0], None, n=batches[0].shape[0], fixed_len=150)
+    assert lib.score_call_end(0) == serial[0]
+    # paired batch in slot 1 while a single-end batch sits in slot 0
+    r1, r2 = synth.make_reads(seqs, 15000, paired=True, seed=300)
+    o = synth.fixed_offsets(r1.shape[0], 150)
+    pe = lib.score_call(r1.reshape(-1), o, r2.reshape(-1), o)
+    lib.score_call_begin(0, flat[1], None, n=batches[1].shape[0], fixed_len=150)
+    lib.score_call_begin(1, r1.reshape(-1), o, r2.reshape(-1), o)
+    assert lib.score_call_end(0) == serial[1]
+    assert lib.score_call_end(1) == pe

@@ -19,9 +19,9 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
+        m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", r["Kernel_Name"])
         if not m or "nimble" not in r["Kernel_Name"]: continue
-        agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[m.group(1) + (m.group(2) or "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as g:
     for k in sorted(agg):
         g.write(k + "\n")
