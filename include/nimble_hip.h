@@ -145,6 +145,24 @@ int nimble_pack(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, co
 int nimble_call_packed(nimble_ctx *, const nimble_align_params *, const nimble_packed *in, uint64_t n,
                        uint32_t max_len);
 
+/* ---- streamed form of the call: ONE score::call whose reads arrive in batches (a FASTQ file larger than one
+ *      buffer; src/process/fastq.rs:15-29 feeds the whole file to a single score::call, so the dedup scope is
+ *      the whole stream).  begin lays the call arrays out for capacity_hint reads (they grow by doubling);
+ *      every append copies its batch to the device on a side stream (overlapping the kernels of the previous
+ *      batch), packs and aligns it; end runs interning, dedup and count over everything.  The getters below
+ *      then behave as after nimble_call over all appended reads, in append order.
+ *      append returns once the batch has left the host buffers (they may be refilled at once); with
+ *      NIMBLE_MEM_DEVICE the buffers must stay untouched until the next append or end returns.
+ *      max_len bounds every read of the stream (it fixes the key width). */
+int nimble_stream_begin(nimble_ctx *, const nimble_align_params *, int paired, uint32_t max_len,
+                        uint64_t capacity_hint);
+int nimble_stream_append(nimble_ctx *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                         const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
+int nimble_stream_end(nimble_ctx *);
+/* page-locked host memory for the batches (full-rate asynchronous H2D) */
+int nimble_pinned_alloc(uint64_t bytes, void **out);
+void nimble_pinned_free(void *);
+
 /* Histogram of the call: one entry per distinct (class of R1, class of R2) over the unique read keys
  * that survived the per-read filters (the `score_map` of src/align.rs:496-505, grouped).
  * class == NIMBLE_CLASS_NONE where that mate has no passing alignment (PairState First/Second).

@@ -75,6 +75,13 @@ int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_of
 int nimble_score_call_begin(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem);
 int nimble_score_call_end(nimble_library *, int slot, nimble_rows **out);
+/* score::call over reads that arrive in batches: ONE call (dedup over everything appended, as process/fastq.rs
+ * feeds a whole file to one score::call); batch i is packed and aligned on the GPU while the caller parses batch
+ * i+1 (nimble_stream_* in nimble_hip.h).  max_len bounds every read of the stream. */
+int nimble_score_stream_begin(nimble_library *, int paired, uint32_t max_len, uint64_t capacity_hint);
+int nimble_score_stream_append(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                               const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
+int nimble_score_stream_end(nimble_library *, nimble_rows **out);
 /* split form of score::call for the multi-GPU driver (see nimble_pack / nimble_call_packed in nimble_hip.h):
  * pack on the rank that holds the reads, exchange the packed arrays, finish on the receiving rank */
 int nimble_library_pack(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
@@ -105,6 +112,11 @@ int nimble_host_revcomp(const char *seq, char *out); /* out holds strlen(seq)+1 
 uint64_t nimble_host_maxinfo(const char *quality, int qlen, uint64_t target_length, double strictness);
 /* read_fastq: n reads, total bases, max length; -1 on the reference's panic */
 int nimble_host_read_fastq(const char *path, uint64_t *n, uint64_t *bases, uint32_t *max_len);
+/* the threaded batch reader of the FASTQ pipeline run to the end: totals, number of batches and an FNV-1a
+ * checksum over (length, bases) of every record in file order; on a malformed record the totals cover the
+ * records before it and the return is -1 with the reference's panic text */
+int nimble_host_read_fastq_batched(const char *path, uint64_t batch_reads, uint64_t *n, uint64_t *bases,
+                                   uint32_t *max_len, uint64_t *n_batches, uint64_t *checksum);
 const char *nimble_host_filter_reason_text(int reason); /* Display for FilterReason */
 
 #ifdef __cplusplus

@@ -73,7 +73,8 @@ HIP_SYMBOLS = [
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
-    "nimble_call_packed", "nimble_ctx_stream",
+    "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
+    "nimble_pinned_alloc", "nimble_pinned_free",
 ]
 
 
@@ -110,6 +111,12 @@ def hip_lib():
         L.nimble_key_words.restype = u32
         L.nimble_pack.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
         L.nimble_call_packed.argtypes = [vp, C.POINTER(AlignParams), C.POINTER(NimblePacked), u64, u32]
+        L.nimble_stream_begin.argtypes = [vp, C.POINTER(AlignParams), i32, u32, u64]
+        L.nimble_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
+        L.nimble_stream_end.argtypes = [vp]
+        L.nimble_pinned_alloc.argtypes = [u64, C.POINTER(vp)]
+        L.nimble_pinned_free.argtypes = [vp]
+        L.nimble_pinned_free.restype = None
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
         _hip = L
@@ -236,6 +243,22 @@ class Context:
                                      fixed_len, max_len, mem))
         self.n = n
 
+    def stream_begin(self, params, paired, max_len, capacity_hint=0):
+        """nimble_stream_begin: open one call whose reads arrive in batches."""
+        _check(hip_lib().nimble_stream_begin(self.h, C.byref(params), int(bool(paired)), max_len, capacity_hint))
+        self.n = 0
+
+    def stream_append(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, mem=MEM_HOST):
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        self._keep = (r1, r1_off, r2, r2_off)
+        _check(hip_lib().nimble_stream_append(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+                                              mem))
+        self.n += n
+
+    def stream_end(self):
+        _check(hip_lib().nimble_stream_end(self.h))
+
     def call_reads(self, params, reads, mates=None):
         b1, o1 = pack_reads(reads)
         if mates is not None:
@@ -303,7 +326,7 @@ HOST_SYMBOLS = [
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
-    "nimble_library_ctx_slot",
+    "nimble_library_ctx_slot", "nimble_host_read_fastq_batched", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
 ]
 
 
@@ -356,6 +379,11 @@ def host_lib():
         L.nimble_score_call_begin.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, u32, i32]
         L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
         L.nimble_library_ctx_slot.argtypes = [vp, i32]
+        L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
+        L.nimble_host_read_fastq_batched.argtypes = [cp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32),
+                                                     C.POINTER(u64), C.POINTER(u64)]
+        L.nimble_score_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
+        L.nimble_score_stream_end.argtypes = [vp, C.POINTER(vp)]
         L.nimble_library_ctx_slot.restype = vp
         L.nimble_library_pack.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
         L.nimble_score_call_packed.argtypes = [vp, C.POINTER(NimblePacked), u64, u32, C.POINTER(vp)]
@@ -592,6 +620,22 @@ class Library:
         _hcheck(host_lib().nimble_score_call_end(self.h, slot, C.byref(h)))
         return RowsHandle(h) if raw else _rows(h)
 
+    def stream_begin(self, paired, max_len, capacity_hint=0):
+        """score::call over reads that arrive in batches (one call: dedup over everything appended)."""
+        _hcheck(host_lib().nimble_score_stream_begin(self.h, int(bool(paired)), max_len, capacity_hint))
+
+    def stream_append(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, mem=MEM_HOST):
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        self._keep = (r1, r1_off, r2, r2_off)
+        _hcheck(host_lib().nimble_score_stream_append(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+                                                      fixed_len, mem))
+
+    def stream_end(self, raw=False):
+        h = C.c_void_p()
+        _hcheck(host_lib().nimble_score_stream_end(self.h, C.byref(h)))
+        return RowsHandle(h) if raw else _rows(h)
+
     def score_call_reads(self, reads, mates=None):
         b1, o1 = pack_reads(reads)
         if mates is not None:
@@ -681,6 +725,14 @@ def read_fastq_stats(path):
     n, b, m = C.c_uint64(), C.c_uint64(), C.c_uint32()
     _hcheck(host_lib().nimble_host_read_fastq(os.fsencode(path), C.byref(n), C.byref(b), C.byref(m)))
     return n.value, b.value, m.value
+
+
+def read_fastq_batched_stats(path, batch_reads):
+    """The pipeline's threaded batch reader run to the end: (records, bases, max_len, batches, checksum)."""
+    n, b, m, nb, h = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+    _hcheck(host_lib().nimble_host_read_fastq_batched(os.fsencode(path), batch_reads, C.byref(n), C.byref(b),
+                                                      C.byref(m), C.byref(nb), C.byref(h)))
+    return n.value, b.value, m.value, nb.value, h.value
 
 
 def filter_reason_text(code):

@@ -103,6 +103,15 @@ struct nimble_ctx {
   uint32_t *p_dyn = nullptr;
   CallBuffers cb{};
   uint64_t bytes = 0;
+  // streamed call (nimble_stream_*): reads arrive in batches, arrays are laid out for `stream_cap` reads
+  bool streaming = false;
+  uint64_t stream_n = 0, stream_cap = 0;
+  uint32_t stream_max_len = 0;
+  hipStream_t h2d_stream = nullptr;
+  DevBuf b_stage[2][2], b_stage_off[2][2];  // [slot][mate]: double-buffered device staging of host batches
+  hipEvent_t ev_h2d[2] = {}, ev_used[2] = {};
+  bool stage_busy[2] = {false, false};
+  int stage_k = 0;
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
@@ -138,8 +147,16 @@ struct nimble_ctx {
                       &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
                       &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
-                      &b_out_cnt})
+                      &b_out_cnt, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
+                      &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
       b->release();
+    if (h2d_stream) {
+      (void)hipStreamDestroy(h2d_stream);
+      for (int k = 0; k < 2; ++k) {
+        (void)hipEventDestroy(ev_h2d[k]);
+        (void)hipEventDestroy(ev_used[k]);
+      }
+    }
     if (have_events)
       for (auto &e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -232,8 +249,8 @@ int enqueue_compact(nimble_ctx *c) {
   return NIMBLE_OK;
 }
 
-// Enqueue the whole launch sequence of one call on the context's stream; nothing here waits for the GPU.
-int enqueue_call(nimble_ctx *c) {
+// Head of a call: clear the per-call tables and counters.
+int enqueue_head(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
   const size_t nn = std::max<uint64_t>(cb.n, 1);
@@ -244,11 +261,13 @@ int enqueue_call(nimble_ctx *c) {
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
   if (!cb.paired) HIPCHK(hipMemsetAsync(cb.len[1], 0, nn * 4, s));
   HIPCHK(hipEventRecord(c->ev[0], s));
-  if (!c->skip_pack)
-    launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
-                c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
-  HIPCHK(hipEventRecord(c->ev[1], s));
-  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters);
+  return NIMBLE_OK;
+}
+
+// Tail of a call, over all cb.n reads: class interning, dedup, count, histogram compaction.
+int enqueue_tail(nimble_ctx *c) {
+  hipStream_t s = c->stream;
+  CallBuffers &cb = c->cb;
   HIPCHK(hipEventRecord(c->ev[2], s));
   // class interning, round 0: claim, then verify behind the kernel boundary.  Tag collisions (practically
   // never) leave reads unresolved; finish_call() then runs further rounds and redoes dedup + count.
@@ -263,6 +282,20 @@ int enqueue_call(nimble_ctx *c) {
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   return mark_done(c);
+}
+
+// Enqueue the whole launch sequence of one call on the context's stream; nothing here waits for the GPU.
+int enqueue_call(nimble_ctx *c) {
+  hipStream_t s = c->stream;
+  CallBuffers &cb = c->cb;
+  int rc = enqueue_head(c);
+  if (rc) return rc;
+  if (!c->skip_pack)
+    launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
+                c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
+  HIPCHK(hipEventRecord(c->ev[1], s));
+  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters);
+  return enqueue_tail(c);
 }
 
 int redo_dedup_count(nimble_ctx *c) {
@@ -655,6 +688,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   if (ext && ext->key_words != kw) return fail(NIMBLE_E_INVALID, "packed buffers: key_words does not match max_len");
   CallBuffers &cb = c->cb;
   cb.n = n;
+  cb.key_stride = n;
   cb.key_words = kw;
   cb.paired = paired ? 1 : 0;
   const size_t nn = std::max<uint64_t>(n, 1);
@@ -797,6 +831,223 @@ int nimble_call_packed(nimble_ctx *c, const nimble_align_params *p, const nimble
   if (rc) return rc;
   c->skip_pack = true;
   return start_call(c);
+}
+
+// ---- streamed call: one score::call whose reads arrive in batches ---------------------------------
+// Arrays are laid out for `stream_cap` reads; every batch packs and aligns its own slice [stream_n,
+// stream_n + m) while the next batch is parsed and copied; dedup and count run once, over everything, at
+// nimble_stream_end -- the dedup scope stays the whole call (src/align.rs:496-505).
+
+static int stream_grow(nimble_ctx *c, uint64_t newcap) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint64_t oldcap = c->stream_cap, used = c->stream_n;
+  const uint32_t kw = c->cb.key_words;
+  auto fresh = [&](DevBuf &nb, size_t bytes) -> int {
+    int rc = nb.ensure(std::max<size_t>(bytes, 16), &c->bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemset(nb.p, 0, bytes));
+    return NIMBLE_OK;
+  };
+  auto swap_in = [&](DevBuf &b, DevBuf &nb) {
+    if (c->bytes >= b.cap) c->bytes -= b.cap;
+    b.release();
+    b = nb;
+    nb.p = nullptr;
+    nb.cap = 0;
+  };
+  {
+    DevBuf nk;
+    int rc = fresh(nk, newcap * kw * 8);
+    if (rc) return rc;
+    if (used)
+      HIPCHK(hipMemcpy2D(nk.p, newcap * 8, c->b_keys.p, oldcap * 8, used * 8, kw, hipMemcpyDeviceToDevice));
+    swap_in(c->b_keys, nk);
+  }
+  auto regrow = [&](DevBuf &b, size_t elem) -> int {
+    DevBuf nb;
+    int rc = fresh(nb, newcap * elem);
+    if (rc) return rc;
+    if (used) HIPCHK(hipMemcpy(nb.p, b.p, used * elem, hipMemcpyDeviceToDevice));
+    swap_in(b, nb);
+    return NIMBLE_OK;
+  };
+  int rc = regrow(c->b_hash, 8);
+  for (int m = 0; m < 2 && !rc; ++m) {
+    rc = regrow(c->b_len[m], 4);
+    if (!rc) rc = regrow(c->b_pre[m], 1);
+    if (!rc) rc = regrow(c->b_reason[m], 1);
+    if (!rc) rc = regrow(c->b_score[m], 4);
+    if (!rc) rc = regrow(c->b_mism[m], 4);
+    if (!rc) rc = regrow(c->b_cls[m], 4);
+    if (!rc) rc = regrow(c->b_dyn_off[m], 4);
+    if (!rc) rc = regrow(c->b_dyn_len[m], 4);
+    if (!rc) rc = regrow(c->b_dyn_hash[m], 8);
+    if (!rc) rc = regrow(c->b_dyn_pos[m], 4);
+  }
+  if (rc) return rc;
+  {  // the pending-class scratch keeps its content; setup_call would otherwise re-allocate it for the new size
+    const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->scratch_cap, env_u64("NIMBLE_SCRATCH_PER_READ", 4) * newcap),
+                                             0xFFFFFF00ULL);
+    if (want > c->scratch_cap) {
+      DevBuf nb;
+      rc = fresh(nb, want * 4);
+      if (rc) return rc;
+      HIPCHK(hipMemcpy(nb.p, c->b_scratch.p, c->scratch_cap * 4, hipMemcpyDeviceToDevice));
+      swap_in(c->b_scratch, nb);
+      c->scratch_cap = want;
+    }
+  }
+  rc = setup_call(c, &c->prm, newcap, c->cb.paired != 0, c->stream_max_len, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, c->stream));
+  c->dedup_clean_slots = 0;
+  c->stream_cap = newcap;
+  return NIMBLE_OK;
+}
+
+int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired, uint32_t max_len,
+                        uint64_t capacity_hint) {
+  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: NULL argument");
+  if (c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: a streamed call is already open");
+  if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: bad max_len");
+  HIPCHK(hipSetDevice(c->ix->device));
+  if (!c->h2d_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_used[k], hipEventDisableTiming));
+    }
+  }
+  const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(capacity_hint, 1ULL << 16), 0xFFFFFFEFULL);
+  int rc = setup_call(c, p, cap, paired != 0, max_len, nullptr);
+  if (rc) return rc;
+  c->prm = *p;
+  c->stream_cap = cap;
+  c->stream_n = 0;
+  c->stream_max_len = max_len;
+  c->stage_busy[0] = c->stage_busy[1] = false;
+  c->stage_k = 0;
+  HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  rc = enqueue_head(c);
+  if (rc) return rc;
+  c->streaming = true;
+  c->finished = true;  // nothing to fetch until nimble_stream_end
+  c->called = false;
+  return NIMBLE_OK;
+}
+
+int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                         const uint64_t *r2_off, uint64_t m, uint32_t fixed_len, int mem) {
+  if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_append: NULL context");
+  if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_append: no streamed call is open");
+  if ((r2 != nullptr) != (c->cb.paired != 0))
+    return fail(NIMBLE_E_INVALID, "nimble_stream_append: mates given for a single-end stream or missing for a paired one");
+  uint32_t max_len = c->stream_max_len;
+  if (!r1_off && fixed_len > max_len)
+    return fail(NIMBLE_E_INVALID, "nimble_stream_append: a read longer than the stream's max_len");
+  int rc = check_read_args(r1, r1_off, r2, r2_off, m, fixed_len, max_len, mem);
+  if (rc) return rc;
+  if (m == 0) return NIMBLE_OK;
+  if (c->stream_n + m >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_stream_append: more than 2^32 reads");
+  HIPCHK(hipSetDevice(c->ix->device));
+  if (c->stream_n + m > c->stream_cap) {
+    rc = stream_grow(c, std::min<uint64_t>(std::max<uint64_t>(2 * c->stream_cap, c->stream_n + m), 0xFFFFFFEFULL));
+    if (rc) return rc;
+  }
+  const uint8_t *in_r[2] = {r1, r2};
+  const uint64_t *in_off[2] = {r1_off, r2_off};
+  const int k = c->stage_k;
+  if (mem == NIMBLE_MEM_HOST) {
+    // device staging slot k: wait until the pack kernel that read it last has run, copy on the side stream
+    // (overlaps the kernels of the previous batch), let the launch stream wait for the copy
+    if (c->stage_busy[k]) HIPCHK(hipEventSynchronize(c->ev_used[k]));
+    for (int mt = 0; mt < (r2 ? 2 : 1); ++mt) {
+      const uint64_t *off = in_off[mt];
+      const uint64_t bytes = off ? off[m] - off[0] : m * (uint64_t)fixed_len;
+      if (off)
+        for (uint64_t i = 0; i < m; ++i)
+          if (off[i + 1] < off[i] || off[i + 1] - off[i] > max_len)
+            return fail(NIMBLE_E_INVALID, "nimble_stream_append: offsets not monotone or a read longer than max_len");
+      rc = c->b_stage[k][mt].ensure(std::max<uint64_t>((off ? off[m] : bytes), 16), &c->bytes);
+      if (rc) return rc;
+      const uint64_t lo = off ? off[0] : 0;
+      if (bytes)
+        HIPCHK(hipMemcpyAsync(c->b_stage[k][mt].as<uint8_t>() + lo, in_r[mt] + lo, bytes, hipMemcpyHostToDevice,
+                              c->h2d_stream));
+      in_r[mt] = c->b_stage[k][mt].as<uint8_t>();
+      if (off) {
+        rc = c->b_stage_off[k][mt].ensure((m + 1) * 8, &c->bytes);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->b_stage_off[k][mt].p, off, (m + 1) * 8, hipMemcpyHostToDevice, c->h2d_stream));
+        in_off[mt] = c->b_stage_off[k][mt].as<uint64_t>();
+      }
+    }
+    HIPCHK(hipEventRecord(c->ev_h2d[k], c->h2d_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[k], 0));
+  }
+  // the batch's view of the call arrays
+  CallBuffers v = c->cb;
+  const uint64_t B = c->stream_n;
+  v.n = m;
+  v.key_stride = c->stream_cap;
+  v.keys += B;
+  v.key_hash += B;
+  v.slot += B;
+  v.counted += B;
+  for (int mt = 0; mt < 2; ++mt) {
+    v.len[mt] += B;
+    v.pre[mt] += B;
+    v.reason[mt] += B;
+    v.score[mt] += B;
+    v.mism[mt] += B;
+    v.cls[mt] += B;
+    v.dyn_off[mt] += B;
+    v.dyn_len[mt] += B;
+    v.dyn_hash[mt] += B;
+    v.dyn_pos[mt] += B;
+  }
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
+  launch_pack(c->stream, in_r[0], in_off[0], in_r[1], in_off[1], fixed_len, max_len, c->prm.min_read_length,
+              c->b_plog.as<double>(), c->plog_max_len, v);
+  if (mem == NIMBLE_MEM_HOST) {
+    HIPCHK(hipEventRecord(c->ev_used[k], c->stream));
+    c->stage_busy[k] = true;
+    c->stage_k ^= 1;
+  }
+  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters);
+  HIPCHK(hipGetLastError());
+  if (mem == NIMBLE_MEM_HOST) HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
+  c->stream_n += m;
+  return NIMBLE_OK;
+}
+
+int nimble_stream_end(nimble_ctx *c) {
+  if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_end: NULL context");
+  if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_end: no streamed call is open");
+  HIPCHK(hipSetDevice(c->ix->device));
+  c->streaming = false;
+  c->cb.n = c->stream_n;
+  c->cb.key_stride = c->stream_cap;
+  c->skip_pack = true;  // a pool regrow in finish_call re-aligns everything from the packed keys
+  c->attempt = 0;
+  HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  int rc = enqueue_tail(c);
+  if (rc) return rc;
+  c->finished = false;
+  c->called = true;
+  return NIMBLE_OK;
+}
+
+int nimble_pinned_alloc(uint64_t bytes, void **out) {
+  if (!out) return fail(NIMBLE_E_INVALID, "nimble_pinned_alloc: NULL argument");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, std::max<uint64_t>(bytes, 16), hipHostMallocDefault);
+  if (e != hipSuccess) return fail(NIMBLE_E_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
+  return NIMBLE_OK;
+}
+
+void nimble_pinned_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 static int finish_count_stage(nimble_ctx *c) { return finish_call(c); }

@@ -37,9 +37,11 @@ struct DevIndex {
   uint32_t *dyn_state;    // [0]=next class id [1]=next free id slot in cls_ids [2]=overflow flag
 };
 
-// per-call device arrays (SoA, stride = n)
+// per-call device arrays (SoA, stride = n; the packed keys have their own stride so that a streamed call can
+// fill a slice [base, base + n) of arrays laid out for the call's capacity)
 struct CallBuffers {
   uint64_t n;
+  uint64_t key_stride;  // reads per key word row (>= n)
   uint32_t key_words;   // words per packed key (R1 ++ R2)
   uint32_t paired;
   uint64_t *keys;       // [key_words][n]

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     nC += (uint32_t)__popcll(~hi & lo);
   };
   auto emit = [&](uint64_t word) {
-    cb.keys[(uint64_t)w * n + r] = word;
+    cb.keys[(uint64_t)w * cb.key_stride + r] = word;
     h = (h ^ word) * 0xff51afd7ed558ccdULL;
     h ^= h >> 32;
     ++w;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
   if (nb) {
     // the last word is left-aligned; its padding is zero = 'A' codes, excluded from the counts above
     const uint64_t word = acc << (64u - 2u * nb);
-    cb.keys[(uint64_t)w * n + r] = word;
+    cb.keys[(uint64_t)w * cb.key_stride + r] = word;
     h = (h ^ word) * 0xff51afd7ed558ccdULL;
     h ^= h >> 32;
   }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
       const uint32_t l1 = nm == 2 ? cb.len[1][r_own] : 0u;
       const uint32_t nw = (l0 + l1 + 31u) >> 5;
       for (uint32_t w = 0; w < kw; ++w)
-        col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * n + r_own) : 0ULL;
+        col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
       col[kw * ALIGN_BLOCK] = 0ULL;
       if (cb.pre[0][r_own] == R_TODO && l0 >= KMER) {
         uint32_t nd = 0, of = 0;
@@ -988,7 +988,7 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t j = (uint32_t)cur;
       bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total;
-      for (uint32_t w = 0; same && w < nw; ++w) same = cb.keys[(uint64_t)w * n + i] == cb.keys[(uint64_t)w * n + j];
+      for (uint32_t w = 0; same && w < nw; ++w) same = cb.keys[(uint64_t)w * cb.key_stride + i] == cb.keys[(uint64_t)w * cb.key_stride + j];
       if (same) {
         atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
         break;

@@ -418,6 +418,34 @@ CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_lib
   return finish_calls(n_reads, index, reference, config, want_per_read, std::chrono::steady_clock::now(), slot);
 }
 
+CallStream::CallStream(PseudoAligner &index, const AlignFilterConfig &config, bool paired, uint32_t max_len,
+                       uint64_t capacity_hint)
+    : index_(index), config_(config), paired_(paired), max_len_(max_len), t0_(std::chrono::steady_clock::now()) {
+  nimble_align_params p = make_params(config);
+  check_rc(nimble_stream_begin(index.ctx(), &p, paired ? 1 : 0, max_len, capacity_hint), "nimble_stream_begin");
+  open_ = true;
+}
+
+CallStream::~CallStream() {
+  if (open_) (void)nimble_stream_end(index_.ctx());  // abandoned (an exception is in flight): just close it
+}
+
+void CallStream::append(const ReadBatch &seqs, const ReadBatch *mates) {
+  if ((mates != nullptr) != paired_ || (mates && mates->n != seqs.n))
+    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  check_rc(nimble_stream_append(index_.ctx(), seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+                                mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len,
+                                seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
+           "nimble_stream_append");
+  n_ += seqs.n;
+}
+
+CallOutput CallStream::finish(const reference_library::Reference &reference, bool want_per_read) {
+  open_ = false;
+  check_rc(nimble_stream_end(index_.ctx()), "nimble_stream_end");
+  return finish_calls(n_, index_, reference, config_, want_per_read, t0_);
+}
+
 CallOutput get_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index,
                      const reference_library::Reference &reference, const AlignFilterConfig &config,
                      bool want_per_read) {

@@ -36,6 +36,7 @@ struct nimble_library {
   align::AlignFilterConfig cfg;
   reference_library::Reference ref;
   std::unique_ptr<align::PseudoAligner> index;
+  std::unique_ptr<align::CallStream> stream;  // nimble_score_stream_begin .. _end
   bool pending[2] = {false, false};  // nimble_score_call_begin without its _end yet
   uint64_t pending_n[2] = {0, 0};
 };
@@ -202,6 +203,43 @@ int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
   });
 }
 
+int nimble_score_stream_begin(nimble_library *l, int paired, uint32_t max_len, uint64_t capacity_hint) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_stream_begin: the library has no index");
+    if (l->stream) throw Panic("nimble_score_stream_begin: a stream is already open");
+    l->stream.reset(new align::CallStream(*l->index, l->cfg, paired != 0, max_len, capacity_hint));
+  });
+}
+
+int nimble_score_stream_append(nimble_library *l, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                               const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem) {
+  return guarded([&] {
+    if (!l->stream) throw Panic("nimble_score_stream_append: no stream is open");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    l->stream->append(b1, r2 ? &b2 : nullptr);
+  });
+}
+
+int nimble_score_stream_end(nimble_library *l, nimble_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->stream) throw Panic("nimble_score_stream_end: no stream is open");
+    std::unique_ptr<align::CallStream> st = std::move(l->stream);
+    align::CallOutput o = st->finish(l->ref);
+    std::sort(o.rows.begin(), o.rows.end(),
+              [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+    *out = make_rows(std::move(o));
+  });
+}
+
 int nimble_library_pack(nimble_library *l, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                         const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                         const nimble_packed *out) {
@@ -320,6 +358,34 @@ int nimble_host_read_fastq(const char *path, uint64_t *n, uint64_t *bases, uint3
     *n = d.n();
     *bases = d.bases.size();
     *max_len = d.max_len;
+  });
+}
+int nimble_host_read_fastq_batched(const char *path, uint64_t batch_reads, uint64_t *n, uint64_t *bases,
+                                   uint32_t *max_len, uint64_t *n_batches, uint64_t *checksum) {
+  return guarded([&] {
+    parse::fastq::BatchReader rd(path, false, (size_t)batch_reads);
+    *n = *bases = *n_batches = 0;
+    *max_len = 0;
+    uint64_t h = 1469598103934665603ULL;
+    for (;;) {
+      std::unique_ptr<parse::fastq::BatchReader::Batch> b = rd.next();
+      *n += b->data.n();
+      *bases += b->data.bases.size();
+      *max_len = std::max(*max_len, b->data.max_len);
+      ++*n_batches;
+      for (uint64_t i = 0; i < b->data.n(); ++i) {  // FNV over (length, bases) of every record, in order
+        h = (h ^ (b->data.offsets[i + 1] - b->data.offsets[i])) * 1099511628211ULL;
+        for (uint64_t k = b->data.offsets[i]; k < b->data.offsets[i + 1]; ++k)
+          h = (h ^ b->data.bases[k]) * 1099511628211ULL;
+      }
+      if (!b->error.empty()) {
+        if (checksum) *checksum = h;
+        throw Panic(b->error);
+      }
+      if (b->last) break;
+      rd.recycle(std::move(b));
+    }
+    if (checksum) *checksum = h;
   });
 }
 const char *nimble_host_filter_reason_text(int r) { return align::to_string((align::FilterReason)r); }

@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <chrono>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -179,6 +180,28 @@ void begin_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, Ps
 CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                      const AlignFilterConfig &config, int slot, bool want_per_read = false);
 
+// get_calls over reads that arrive in batches (one call, dedup over everything appended): the FASTQ pipeline
+// parses batch i+1 while the GPU packs and aligns batch i (include/nimble_hip.h: nimble_stream_*).
+class CallStream {
+ public:
+  CallStream(PseudoAligner &index, const AlignFilterConfig &config, bool paired, uint32_t max_len,
+             uint64_t capacity_hint);
+  ~CallStream();
+  void append(const ReadBatch &sequences, const ReadBatch *mate_sequences);
+  uint64_t reads() const { return n_; }
+  uint32_t max_len() const { return max_len_; }
+  // closes the stream and returns the rows of get_calls over all appended reads (unsorted)
+  CallOutput finish(const reference_library::Reference &reference, bool want_per_read = false);
+
+ private:
+  PseudoAligner &index_;
+  AlignFilterConfig config_;
+  bool paired_, open_ = false;
+  uint32_t max_len_;
+  uint64_t n_ = 0;
+  std::chrono::steady_clock::time_point t0_;
+};
+
 // Split form used by the multi-GPU driver: pack where the reads are, exchange the packed form, run the rest
 // of get_calls on the receiving rank (include/nimble_hip.h: nimble_pack / nimble_call_packed).
 void pack_reads(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
@@ -228,6 +251,28 @@ struct FastqData {
 // Panics with "Error -- could not parse read. Input R1 data malformed." (src/align.rs:517) /
 // "... reverse read. Input R2 data malformed." (src/align.rs:541) on a malformed record.
 FastqData read_fastq(const std::string &path, bool is_mate);
+
+// The same reader, incremental: a thread parses ahead and hands over batches of `batch_reads` records in file
+// order.  A malformed record ends the file: the batch before it carries the records that parsed and the
+// reference's panic text in `error` (the consumer decides when that panic fires, as the reference's lazy
+// iterators would).
+class BatchReader {
+ public:
+  struct Batch {
+    FastqData data;
+    bool last = false;        // no further batch follows (end of file, or `error`)
+    std::string error;        // panic text of the malformed record that follows data, if any
+    uint64_t raw_offset = 0;  // (compressed) file bytes consumed when the batch was closed
+  };
+  BatchReader(const std::string &path, bool is_mate, size_t batch_reads);
+  ~BatchReader();
+  std::unique_ptr<Batch> next();            // blocks until the next batch is parsed
+  void recycle(std::unique_ptr<Batch> b);  // hand the buffers back for reuse
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
 }  // namespace fastq
 }  // namespace parse
 

@@ -228,3 +228,154 @@ def test_two_calls_in_flight_match_serial_calls(synth_lib):
     lib.score_call_begin(1, r1.reshape(-1), o, r2.reshape(-1), o)
     assert lib.score_call_end(0) == serial[1]
     assert lib.score_call_end(1) == pe
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_streamed_call_equals_one_call(synth_lib, paired):
+    # one score::call fed in batches (nimble_stream_*): identical rows, per-read records in append order;
+    # small capacity hint so the call arrays grow (re-pitch of the key planes) several times
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    n = 150_000
+    if paired:
+        r1, r2 = synth.make_reads(seqs, n, paired=True, seed=501)
+    else:
+        r1, r2 = synth.make_reads(seqs, n, seed=500), None
+    o = synth.fixed_offsets(n, 150)
+    whole = lib.score_call(r1.reshape(-1), o, None if r2 is None else r2.reshape(-1), None if r2 is None else o)
+    ctx = lib.device_context()
+    ctx.n = n
+    rec_whole = [ctx.read_records(m) for m in range(2 if paired else 1)]
+    hist_whole = ctx.histogram()
+    cuts = [0, 1, 257, 20_000, 20_001, 90_000, 149_999, n]   # ragged batches, including 1-read ones
+    lib.stream_begin(paired, 150, capacity_hint=1)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        f1 = np.ascontiguousarray(r1[a:b].reshape(-1))
+        if paired:
+            f2 = np.ascontiguousarray(r2[a:b].reshape(-1))
+            if a % 2:   # alternate between offsets and fixed length batches
+                lib.stream_append(f1, None, f2, None, n=b - a, fixed_len=150)
+            else:
+                ob = synth.fixed_offsets(b - a, 150)
+                lib.stream_append(f1, ob, f2, ob)
+        else:
+            lib.stream_append(f1, None, n=b - a, fixed_len=150)
+    got = lib.stream_end()
+    assert got == whole
+    ctx.n = n
+    assert ctx.histogram() == hist_whole
+    for m in range(2 if paired else 1):
+        rec = ctx.read_records(m)
+        for k in ("reason", "score", "mismatches", "cls", "counted"):
+            if k in rec:
+                np.testing.assert_array_equal(rec[k], rec_whole[m][k], err_msg=k)
+    # empty stream
+    lib.stream_begin(paired, 150)
+    assert lib.stream_end() == []
+    with pytest.raises(nim.Panic, match="no stream is open"):
+        lib.stream_end()
+
+
+def test_streamed_call_device_batches_and_variable_lengths(synth_lib):
+    torch = pytest.importorskip("torch")
+    path, seqs = synth_lib
+    lib = nim.Library(path, "none").build_index()
+    rng = np.random.default_rng(9)
+    reads = synth.make_reads(seqs, 40_000, seed=77)
+    lens = rng.integers(20, 151, size=reads.shape[0])
+    lens[::97] = 0   # empty records
+    strs = [bytes(reads[i, : lens[i]]) for i in range(reads.shape[0])]
+    flat, off = nim.pack_reads(strs)
+    whole = lib.score_call(flat, off)
+    lib.stream_begin(False, 150, capacity_hint=1000)
+    step = 7_001
+    for a in range(0, len(strs), step):
+        fb, ob = nim.pack_reads(strs[a:a + step])
+        lib.stream_append(fb, ob)
+    assert lib.stream_end() == whole
+    # device-resident fixed-length batches
+    fixed = synth.make_reads(seqs, 30_000, seed=78)
+    whole = lib.score_call(fixed.reshape(-1), None, n=fixed.shape[0], fixed_len=150)
+    dev = torch.from_numpy(fixed.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    lib.stream_begin(False, 150, capacity_hint=30_000)
+    for a in range(0, 30_000, 10_000):
+        lib.stream_append(dev[a:a + 10_000], None, n=10_000, fixed_len=150, mem=nim.MEM_DEVICE)
+    assert lib.stream_end() == whole
+    with pytest.raises(nim.Panic, match="longer than"):
+        lib.stream_begin(False, 100)
+        try:
+            lib.stream_append(fixed.reshape(-1), None, n=10, fixed_len=150)
+        finally:
+            lib.stream_end()
+
+
+def test_fastq_pipeline_streams_batches(synth_lib, tmp_path, monkeypatch):
+    # process::fastq::process with small ingest batches: same TSV as the oracle; how the run ends when the
+    # two files disagree follows the reference's pull order (R1 record i, then R2 record i)
+    path, seqs = synth_lib
+    n = 3108  # 4 * 777: R1 ends exactly on a batch boundary
+    r1, r2 = synth.make_reads(seqs, n, paired=True, seed=41)
+    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    exp = oracle_rows(path, "unstranded", r1, r2)
+    want = "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
+    lib = nim.Library(path, "unstranded").build_index()
+    for batch in ("777", "1000", "1", "0"):
+        monkeypatch.setenv("NIMBLE_FASTQ_BATCH", batch)
+        if batch == "1" and n > 500:
+            continue  # covered by the reader test; one-read batches over thousands of reads are only slow
+        out = str(tmp_path / ("out_%s.tsv" % batch))
+        nim.fastq_process([f1, f2], [lib], [out])
+        assert open(out).read() == want, batch
+    monkeypatch.setenv("NIMBLE_FASTQ_BATCH", "777")
+    # two libraries fed from one pass over the files
+    lib_b = nim.Library(os.path.join(GOLDEN, "libraries", "basic.json"), "unstranded").build_index()
+    o1, o2 = str(tmp_path / "m1.tsv"), str(tmp_path / "m2.tsv")
+    nim.fastq_process([f1, f2], [lib, lib_b], [o1, o2])
+    assert open(o1).read() == want and open(o2).read() == "feature\tscore\n"
+    # R2 longer than R1: extra records are never pulled
+    f2_long = str(tmp_path / "r2_long.fastq")
+    synth.write_fastq(f2_long, np.concatenate([r2, r2[:50]]))
+    out = str(tmp_path / "long.tsv")
+    nim.fastq_process([f1, f2_long], [lib], [out])
+    assert open(out).read() == want
+    # R2 shorter: the reference panics when the missing mate is pulled
+    f2_short = str(tmp_path / "r2_short.fastq")
+    synth.write_fastq(f2_short, r2[:2000])
+    with pytest.raises(nim.Panic, match="do not have matching lengths"):
+        nim.fastq_process([f1, f2_short], [lib], [str(tmp_path / "x.tsv")])
+    # malformed records: the one with the smaller record index decides, R1 on a tie
+    def corrupt(src, dst, rec):
+        lines = open(src).read().split("\n")
+        lines[4 * rec] = "broken header"
+        open(dst, "w").write("\n".join(lines))
+    b1, b2 = str(tmp_path / "b1.fastq"), str(tmp_path / "b2.fastq")
+    corrupt(f1, b1, 2000)
+    corrupt(f2, b2, 10)
+    with pytest.raises(nim.Panic, match="Input R2 data malformed"):
+        nim.fastq_process([b1, b2], [lib], [str(tmp_path / "x.tsv")])
+    corrupt(f1, b1, 10)
+    corrupt(f2, b2, 2000)
+    with pytest.raises(nim.Panic, match="Input R1 data malformed"):
+        nim.fastq_process([b1, b2], [lib], [str(tmp_path / "x.tsv")])
+    corrupt(f2, b2, 10)
+    with pytest.raises(nim.Panic, match="Input R1 data malformed"):
+        nim.fastq_process([b1, b2], [lib], [str(tmp_path / "x.tsv")])
+    assert not os.path.exists(str(tmp_path / "x.tsv"))
+    # a longer read shows up after the stream was opened: the pipeline falls back to the whole-file call
+    monkeypatch.setenv("NIMBLE_FASTQ_BATCH", "500")
+    mixed = str(tmp_path / "mixed.fastq")
+    short = synth.make_reads(seqs, 1200, seed=43)[:, :100]
+    longr = synth.make_reads(seqs, 800, seed=44)
+    with open(mixed, "w") as f:
+        for i, r in enumerate(list(short) + list(longr)):
+            f.write("@m%d\n%s\n+\n%s\n" % (i, bytes(r).decode(), "I" * len(r)))
+    strs = [bytes(r) for r in short] + [bytes(r) for r in longr]
+    flat, off = nim.pack_reads(strs)
+    cfg, ref = ora.get_reference_library(path, "unstranded")
+    exp = ora.call(ora.Index.from_reference(ref), ref, cfg, flat, off).rows
+    out = str(tmp_path / "mixed.tsv")
+    nim.fastq_process([mixed], [lib], [out])
+    assert open(out).read() == "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)

@@ -285,6 +285,50 @@ def test_read_fastq_fixtures_and_gzip(tmp_path):
     assert nim.read_fastq_stats(str(multi)) == (2, 8, 6)
 
 
+def _fnv_records(records):
+    h = 1469598103934665603
+    for r in records:
+        h = ((h ^ len(r)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        for c in r:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_batched_fastq_reader_matches_whole_file_reader(tmp_path):
+    # the pipeline's threaded reader: same records in the same order for every batch size, plain and gzip,
+    # lines that straddle the read window, a malformed record after N good ones
+    rng = np.random.default_rng(3)
+    recs = [bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(0, 300))).astype(np.uint8)) for _ in range(5000)]
+    recs[17] = b""          # empty sequence line
+    text = b"".join(b"@r%d some description\n%s\n+\n%s\n" % (i, r, b"I" * max(len(r), 1)) for i, r in enumerate(recs))
+    plain = tmp_path / "x.fastq"
+    plain.write_bytes(text)
+    gz = tmp_path / "x.fastq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(text)
+    n, bases, max_len = nim.read_fastq_stats(str(plain))
+    assert (n, bases, max_len) == (len(recs), sum(map(len, recs)), max(map(len, recs)))
+    want = _fnv_records(recs)
+    for path in (plain, gz):
+        for batch in (1, 7, 1000, 4999, 5000, 5001, 1 << 20):
+            got = nim.read_fastq_batched_stats(str(path), batch)
+            assert got[:3] == (n, bases, max_len) and got[4] == want
+            assert got[3] == len(recs) // batch + 1          # a final (possibly empty) batch closes the file
+    # a very long line (longer than the 4 MiB window) and CRLF line ends
+    big = tmp_path / "big.fastq"
+    long_read = b"ACGT" * (3 << 20)
+    big.write_bytes(b"@a\r\nAC\r\n+\r\nII\r\n@b\n" + long_read + b"\n+\n" + b"I" * 10 + b"\n")
+    got = nim.read_fastq_batched_stats(str(big), 1)
+    assert got[:3] == (2, 2 + len(long_read), len(long_read)) and got[4] == _fnv_records([b"AC", long_read])
+    # malformed after 3 good records: the panic of the reference, raised after the good records were delivered
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@a\nAC\n+\nII\n@b\nGG\n+\nII\n@c\nTT\n+\nII\nnot a header\nAC\n+\nII\n")
+    with pytest.raises(nim.Panic, match="Input R1 data malformed.: Unable to read sequence"):
+        nim.read_fastq_batched_stats(str(bad), 2)
+    with pytest.raises(nim.Panic, match="could not determine compression format"):
+        nim.read_fastq_batched_stats(str(tmp_path / "missing.fastq"), 2)
+
+
 def test_synthetic_generator_is_deterministic():
     n1, s1 = synth.make_library(8)
     n2, s2 = synth.make_library(8)
