@@ -137,6 +137,7 @@ struct nimble_ctx {
   uint64_t dedup_clean_slots = 0;  // slots [0, this) of b_dedup are known to be zero (cleared at the tail of the last call)
   bool finished = true;
   bool skip_pack = false;  // the call started from packed keys (nimble_call_packed)
+  bool counted_marked = true;  // the `counted` flags of the last call are valid (k_count ran)
   int attempt = 0;
   std::vector<uint64_t> h_state = std::vector<uint64_t>(16, 0);
   std::vector<uint32_t> h_c1, h_c2;  // histogram of the last finished call, sorted by (c1, c2)
@@ -276,7 +277,8 @@ int enqueue_tail(nimble_ctx *c) {
   HIPCHK(hipEventRecord(c->ev[3], s));
   launch_dedup(s, c->prm, cb);
   HIPCHK(hipEventRecord(c->ev[4], s));
-  launch_count(s, cb);
+  if (!cb.fuse_count) launch_count(s, cb);
+  c->counted_marked = !cb.fuse_count;
   HIPCHK(hipEventRecord(c->ev[5], s));
   int rc = enqueue_compact(c);
   if (rc) return rc;
@@ -307,7 +309,8 @@ int redo_dedup_count(nimble_ctx *c) {
   HIPCHK(hipEventRecord(c->ev[3], s));
   launch_dedup(s, c->prm, c->cb);
   HIPCHK(hipEventRecord(c->ev[4], s));
-  launch_count(s, c->cb);
+  if (!c->cb.fuse_count) launch_count(s, c->cb);
+  c->counted_marked = !c->cb.fuse_count;
   HIPCHK(hipEventRecord(c->ev[5], s));
   int rc = enqueue_compact(c);
   return rc ? rc : mark_done(c);
@@ -367,8 +370,8 @@ int finish_call(nimble_ctx *c) {
     }
     break;
   }
-  // histogram entries to the host (sorted by class pair), then clear the dedup table for the next call: the
-  // memset runs on the stream while the host turns the histogram into rows
+  // histogram entries to the host (sorted by class pair).  The dedup table stays as it is until the next call
+  // clears it: nimble_read_records may still need it to mark the representatives.
   {
     const uint64_t ne = c->h_state[11];
     c->h_c1.resize(ne);
@@ -392,8 +395,6 @@ int finish_call(nimble_ctx *c) {
         c->h_cnt[i] = k[idx[i]];
       }
     }
-    HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, c->stream));
-    c->dedup_clean_slots = c->dslots;
   }
   c->dyn_before = c->p_dyn[0];  // copied at the head of the call, ahead of everything fetch_state waited for
   c->finished = true;
@@ -691,6 +692,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   cb.key_stride = n;
   cb.key_words = kw;
   cb.paired = paired ? 1 : 0;
+  cb.fuse_count = paired ? 0u : 1u;  // single-end: classes are a function of the dedup key (see k_dedup)
   const size_t nn = std::max<uint64_t>(n, 1);
   int rc = NIMBLE_OK;
   auto need = [&](DevBuf &b, size_t bytes) {
@@ -794,6 +796,8 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc) return rc;
   rc = setup_call(c, p, n, r2 != nullptr, max_len, nullptr);
   if (rc) return rc;
+  // classes are a function of the dedup key when the key fixes where R1 ends: single-end, or fixed-length mates
+  c->cb.fuse_count = (!r2 || !r1_off) ? 1u : 0u;
   c->skip_pack = false;
   return start_call(c);
 }
@@ -829,6 +833,7 @@ int nimble_call_packed(nimble_ctx *c, const nimble_align_params *p, const nimble
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = setup_call(c, p, n, in->paired != 0, max_len, in);
   if (rc) return rc;
+  c->cb.fuse_count = in->paired ? 0u : 1u;
   c->skip_pack = true;
   return start_call(c);
 }
@@ -1091,6 +1096,12 @@ int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score
   int rc = finish_count_stage(c);
   if (rc) return rc;
   if (n == 0) return NIMBLE_OK;
+  if (counted && !c->counted_marked) {
+    // the call counted inside k_dedup; the flags of the representatives (last copy of each key) are made now
+    launch_count(c->stream, c->cb);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->counted_marked = true;
+  }
   if (mate == 1 && !c->cb.paired) {
     for (uint64_t i = 0; i < n; ++i) {
       if (reason) reason[i] = NIMBLE_R_SUCCESSFUL_MATCH;  // src/align.rs:596-599: no mate filter -> SuccessfulMatch

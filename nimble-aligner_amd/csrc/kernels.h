@@ -59,6 +59,7 @@ struct CallBuffers {
   uint32_t *dyn_pos[2];   // intern slot claimed / matched in the last round
   uint32_t *slot;         // dedup slot per read or SLOT_NONE
   uint8_t *counted;
+  uint32_t fuse_count;    // k_dedup counts the first copy of every key itself (k_count then only marks `counted`)
   uint32_t *scratch;      // pending class ids of this call
   uint32_t scratch_cap;
   uint32_t *ws_cols;      // overflow of the per-lane visited-colour list: [rows][lanes]

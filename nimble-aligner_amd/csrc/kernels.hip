@@ -953,6 +953,23 @@ __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
   else atomicAdd((unsigned long long *)&cb.state[9], 1ULL);  // tag collision: next round probes further
 }
 
+// one unique read key adds 1 to the (class R1, class R2) histogram (open addressing over u64 keys)
+__device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t c1, uint32_t c2) {
+  const uint64_t key = ((uint64_t)c1 << 32) | c2;
+  uint64_t pos = mix64(key) & cb.hist_mask;
+  for (uint64_t probes = 0; probes <= cb.hist_mask; ++probes) {
+    uint64_t cur = cb.hist_keys[pos];  // almost always already present: skip the CAS
+    if (cur != key)
+      cur = atomicCAS((unsigned long long *)&cb.hist_keys[pos], (unsigned long long)HIST_EMPTY, (unsigned long long)key);
+    if (cur == HIST_EMPTY || cur == key) {
+      atomicAdd((unsigned long long *)&cb.hist_cnt[pos], 1ULL);
+      return;
+    }
+    pos = (pos + 1) & cb.hist_mask;
+  }
+  atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_HIST);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_dedup: pair filter + insert of the read key into the call's dedup table (last writer wins)
 // ---------------------------------------------------------------------------------------------
@@ -984,7 +1001,12 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
   uint32_t pos = __umulhi((uint32_t)h, cb.dedup_slots);  // low hash half picks the slot, high half is the tag
   for (;;) {
     uint64_t cur = atomicCAS((unsigned long long *)&cb.dedup[pos], 0ULL, (unsigned long long)mine);
-    if (cur == 0) break;
+    if (cur == 0) {
+      // first copy of this key.  When the classes are a function of the key alone (single-end, or mates of one
+      // fixed length) any copy may stand for the key in the histogram, so count it here and skip k_count.
+      if (cb.fuse_count) hist_add(cb, c1, c2);
+      break;
+    }
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t j = (uint32_t)cur;
       bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total;
@@ -999,7 +1021,8 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
   cb.slot[i] = (uint32_t)pos;
 }
 
-// k_count: the representative of each key adds one to the (class R1, class R2) histogram
+// k_count: the representative of each key adds one to the (class R1, class R2) histogram.  When k_dedup has
+// already counted (fuse_count), only the `counted` flags are set here, and only when somebody asks for them.
 __global__ void k_count(CallBuffers cb) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cb.n) return;
@@ -1007,20 +1030,8 @@ __global__ void k_count(CallBuffers cb) {
   if (s == SLOT_NONE) return;
   if ((uint32_t)cb.dedup[s] != (uint32_t)i) return;
   cb.counted[i] = 1;
-  const uint32_t c1 = cb.cls[0][i];
-  const uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
-  const uint64_t key = ((uint64_t)c1 << 32) | c2;
-  uint64_t pos = mix64(key) & cb.hist_mask;
-  for (uint64_t probes = 0; probes <= cb.hist_mask; ++probes) {
-    uint64_t cur = atomicCAS((unsigned long long *)&cb.hist_keys[pos], (unsigned long long)HIST_EMPTY,
-                             (unsigned long long)key);
-    if (cur == HIST_EMPTY || cur == key) {
-      atomicAdd((unsigned long long *)&cb.hist_cnt[pos], 1ULL);
-      return;
-    }
-    pos = (pos + 1) & cb.hist_mask;
-  }
-  atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_HIST);
+  if (cb.fuse_count) return;
+  hist_add(cb, cb.cls[0][i], cb.paired ? cb.cls[1][i] : CLS_NONE);
 }
 
 __global__ void k_hist_compact(CallBuffers cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt, uint64_t cap) {

@@ -369,14 +369,22 @@ void process(const std::vector<std::string> &input_files,
   size_t batch = 1u << 19;
   if (const char *e = getenv("NIMBLE_FASTQ_BATCH")) batch = (size_t)strtoull(e, nullptr, 10);
   if (batch == 0 || reference_indices.empty()) {
+    const auto t0 = std::chrono::steady_clock::now();
     whole_file(input_files, reference_indices, references, aligner_configs, output_paths);
+    if (getenv("NIMBLE_HOST_TIMING"))
+      fprintf(stderr, "[nimble host] fastq pipeline (parse + device + tsv) %.3f s, whole file first\n",
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return;
   }
+  const auto t0 = std::chrono::steady_clock::now();
   try {
     streamed(input_files, reference_indices, references, aligner_configs, output_paths, batch);
   } catch (const NeedWholeFile &) {
     whole_file(input_files, reference_indices, references, aligner_configs, output_paths);
   }
+  if (getenv("NIMBLE_HOST_TIMING"))
+    fprintf(stderr, "[nimble host] fastq pipeline (parse + device + tsv) %.3f s, ingest batch %zu records\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), batch);
 }
 
 }  // namespace fastq
