@@ -83,7 +83,14 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     uint32_t nvec = (uint32_t)((e - s + shift[m] + 15) >> 4);
     uint4 *dst = reinterpret_cast<uint4 *>(lds + (size_t)m * tile_bytes);
     const uint4 *g = reinterpret_cast<const uint4 *>(a0);
-    for (uint32_t i = tid; i < nvec; i += PACK_BLOCK) dst[i] = g[i];  // 16 B / lane, coalesced
+    // 16 B / lane, coalesced, written to LDS by the load itself (global_load_lds_dwordx4: wave-uniform LDS base +
+    // lane * 16): every load of the tile is in flight before the single wait in front of the barrier
+    for (uint32_t base = 0; base < nvec; base += PACK_BLOCK) {
+      const uint32_t i = base + tid;
+      if (i < nvec)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i),
+                                         (__attribute__((address_space(3))) void *)(dst + (base + (tid & ~63u))), 16, 0, 0);
+    }
   }
   __syncthreads();
   if (tid >= cnt) return;
@@ -134,18 +141,43 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     const uint32_t len = L[m];
     uint32_t prev = q[0];
     uint32_t i = 0;
-    for (uint32_t done = 0; done < len; done += 4, ++i) {
-      const uint32_t next = q[i + 1];
-      const uint32_t raw = __builtin_amdgcn_alignbyte(next, prev, mis);  // bytes done .. done+3 of the read
-      prev = next;
+    // 4 ASCII bytes (first base in the low byte) -> 8 bits of 2-bit codes, first base highest
+    auto conv4 = [&](uint32_t raw) -> uint32_t {
       const uint32_t x = raw | 0x20202020u;                 // lower-case
       uint32_t code = (x >> 1) & 0x03030303u;               // a->0 c->1 g->3 t->2
       code ^= (code >> 1) & 0x01010101u;                    // a->0 c->1 g->2 t->3
       const uint32_t letter = __builtin_amdgcn_perm(0u, 0x74676361u, code);  // code -> 'a','c','g','t'
       const uint32_t d = letter ^ x;                        // zero byte <=> a valid base
-      const uint32_t zb = ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);  // 0x80 where valid
-      code &= (zb >> 7) * 0xFFu;                            // anything else encodes as 'A' (0)
-      const uint32_t packed = (code * 0x40100401u) >> 24;   // 4 codes -> 8 bits, first base highest
+      if (d) {                                              // rare: something that is not A/C/G/T encodes as 'A' (0)
+        const uint32_t zb = ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);  // 0x80 where valid
+        code &= (zb >> 7) * 0xFFu;
+      }
+      return (code * 0x40100401u) >> 24;
+    };
+    auto fetch4 = [&]() -> uint32_t {                       // next 4 bytes of the read
+      const uint32_t next = q[++i];
+      const uint32_t raw = __builtin_amdgcn_alignbyte(next, prev, mis);
+      prev = next;
+      return raw;
+    };
+    uint32_t done = 0;
+    // whole 32-base groups: the word is assembled with constant shifts and meets the pending bases once
+    for (; done + 32u <= len; done += 32u) {
+      uint32_t hi = 0, lo = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi = (hi << 8) | conv4(fetch4());
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lo = (lo << 8) | conv4(fetch4());
+      const uint64_t w32 = ((uint64_t)hi << 32) | lo;
+      if (nb == 0) {
+        emit(w32);
+      } else {
+        emit((acc << (64u - 2u * nb)) | (w32 >> (2u * nb)));
+        acc = w32 & ((1ULL << (2u * nb)) - 1ULL);
+      }
+    }
+    for (; done < len; done += 4) {
+      const uint32_t packed = conv4(fetch4());
       const uint32_t k = len - done < 4u ? len - done : 4u;
       append(packed >> (2u * (4u - k)), k);
     }
