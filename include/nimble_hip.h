@@ -42,6 +42,7 @@ enum {
   NIMBLE_R_HIGH_ENTROPY = 10,
   NIMBLE_R_SUCCESSFUL_MATCH = 11,
   NIMBLE_R_ABOVE_MISMATCH_THRESHOLD = 14,
+  NIMBLE_R_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY = 15,
   NIMBLE_R_NONE = 16
 };
 
@@ -123,6 +124,38 @@ enum { NIMBLE_MEM_HOST = 0, NIMBLE_MEM_DEVICE = 1 };
 int nimble_call(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, const uint64_t *r1_off,
                 const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len,
                 int mem);
+
+/* ---- the call as the BAM pipeline makes it (src/process/bam.rs:183-226,229-290; src/align.rs:516-552): many
+ *      UMI groups in one launch, reads trimmed for quality before they are aligned, unpaired dummies skipped.
+ *      Every field is optional (NULL / 0 = absent); the arrays live in the same memory space as the reads.
+ *
+ *  segment   [n] scope id per read(-pair): the reference calls score::call once per UMI, so the dedup of
+ *            src/align.rs:685 and the per-callset counts are per segment.  Ids need not be sorted or dense;
+ *            n_segments must exceed the largest id (0 = take it from the array, host memory only).
+ *  qual      quality strings laid out exactly like the bases (same offsets / fixed_len).  Each mate is aligned on
+ *            its first maxinfo(quality, trim_target_length, trim_strictness) bases (trim_sequence,
+ *            src/align.rs:866-942) while the dedup key stays the untrimmed read (src/align.rs:576-579).
+ *  skip      [n] per mate: non-zero = SKIP_ALIGN dummy (src/align.rs:527-528,549-550): not aligned, reason
+ *            NIMBLE_R_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY. */
+typedef struct nimble_call_extra {
+  const uint32_t *segment;
+  uint32_t n_segments;
+  uint32_t reserved;
+  const uint8_t *qual[2];
+  double trim_strictness;
+  uint64_t trim_target_length;
+  const uint8_t *skip[2];
+} nimble_call_extra;
+int nimble_call_ex(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, const uint64_t *r1_off,
+                   const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len,
+                   int mem, const nimble_call_extra *extra);
+/* Histogram of a segmented call: one entry per distinct (segment, class R1, class R2), sorted that way, with the
+ * number of unique read keys and one representative read index (the reference keeps the metadata of one read per
+ * callset, src/align.rs:245-251).  After a call without segments every entry has segment 0. */
+int nimble_histogram_seg(nimble_ctx *, uint32_t *segment, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count,
+                         uint32_t *representative, uint64_t cap, uint64_t *n_entries);
+/* bases of each mate that were aligned (the read length unless the call trimmed for quality) */
+int nimble_read_align_len(nimble_ctx *, int mate, uint32_t *align_len, uint64_t n);
 
 /* ---- split form of the call, for multi-GPU runs: reads are packed where they are, exchanged between
  *      ranks in packed form (40 B instead of 150 B per read; the key hash that routes them is a function of

@@ -75,6 +75,31 @@ int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_of
 int nimble_score_call_begin(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem);
 int nimble_score_call_end(nimble_library *, int slot, nimble_rows **out);
+/* The BAM pipeline's calls (src/process/bam.rs:183-226,229-290): the reference runs score::call once per UMI
+ * group with the reads' BAM metadata; here a whole batch of groups is ONE device call.  `extra` (all fields
+ * optional) carries the group id per read(-pair), the quality strings for trim_sequence (src/align.rs:866-871,
+ * trim settings from the library's config) and the SKIP_ALIGN flags (src/align.rs:527-528).  Rows: per group, the
+ * callsets of get_calls with their counts and one representative read (whose BAM fields the caller reports,
+ * src/align.rs:245-251), sorted by (group, callset).  With want_per_read, the filter_reasons entry of every read:
+ * {r1 reason, r1 score, r2 reason, r2 score, triage reason} (src/align.rs:453-458); orientation is always None. */
+typedef struct nimble_umi_extra {
+  const uint32_t *segment;
+  uint32_t n_segments;
+  uint32_t reserved;
+  const uint8_t *qual[2];
+  const uint8_t *skip[2];
+} nimble_umi_extra;
+typedef struct nimble_umi_rows nimble_umi_rows;
+int nimble_score_call_umis(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                           const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                           const nimble_umi_extra *extra, int want_per_read, nimble_umi_rows **out);
+void nimble_umi_rows_free(nimble_umi_rows *);
+uint64_t nimble_umi_rows_count(const nimble_umi_rows *);
+const char *nimble_umi_rows_get(const nimble_umi_rows *, uint64_t i, uint32_t *segment, int32_t *count,
+                                uint32_t *representative);
+uint64_t nimble_umi_rows_reads(const nimble_umi_rows *);
+int nimble_umi_rows_filter(const nimble_umi_rows *, uint64_t read, int32_t out[5]);
+
 /* score::call over reads that arrive in batches: ONE call (dedup over everything appended, as process/fastq.rs
  * feeds a whole file to one score::call); batch i is packed and aligned on the GPU while the caller parses batch
  * i+1 (nimble_stream_* in nimble_hip.h).  max_len bounds every read of the stream. */

@@ -66,6 +66,19 @@ class NimblePacked(C.Structure):
     ]
 
 
+class CallExtra(C.Structure):
+    """struct nimble_call_extra (include/nimble_hip.h): what the BAM pipeline adds to a call."""
+    _fields_ = [("segment", C.c_void_p), ("n_segments", C.c_uint32), ("reserved", C.c_uint32),
+                ("qual", C.c_void_p * 2), ("trim_strictness", C.c_double), ("trim_target_length", C.c_uint64),
+                ("skip", C.c_void_p * 2)]
+
+
+class UmiExtra(C.Structure):
+    """struct nimble_umi_extra (include/nimble_host.h)."""
+    _fields_ = [("segment", C.c_void_p), ("n_segments", C.c_uint32), ("reserved", C.c_uint32),
+                ("qual", C.c_void_p * 2), ("skip", C.c_void_p * 2)]
+
+
 _hip = None
 
 HIP_SYMBOLS = [
@@ -74,7 +87,7 @@ HIP_SYMBOLS = [
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
     "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
-    "nimble_pinned_alloc", "nimble_pinned_free",
+    "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
 ]
 
 
@@ -117,6 +130,9 @@ def hip_lib():
         L.nimble_pinned_alloc.argtypes = [u64, C.POINTER(vp)]
         L.nimble_pinned_free.argtypes = [vp]
         L.nimble_pinned_free.restype = None
+        L.nimble_call_ex.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(CallExtra)]
+        L.nimble_histogram_seg.argtypes = [vp, vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+        L.nimble_read_align_len.argtypes = [vp, i32, vp, u64]
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
         _hip = L
@@ -243,6 +259,50 @@ class Context:
                                      fixed_len, max_len, mem))
         self.n = n
 
+    def call_ex(self, params, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST,
+                segment=None, n_segments=0, qual=(None, None), skip=(None, None), trim_strictness=0.0,
+                trim_target_length=0):
+        """nimble_call_ex: the call as the BAM pipeline makes it (UMI segments, quality trim, SKIP_ALIGN)."""
+        if r1_off is not None:
+            n = int(len(r1_off) - 1) if n is None else n
+        if max_len == 0:
+            if r1_off is not None and isinstance(r1_off, np.ndarray):
+                max_len = int(np.diff(r1_off.astype(np.int64)).max()) if n else 1
+                if r2_off is not None:
+                    max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()) if n else 1)
+            else:
+                max_len = fixed_len
+        ex = CallExtra()
+        ex.segment = _ptr(segment)
+        ex.n_segments = n_segments
+        for m in range(2):
+            ex.qual[m] = _ptr(qual[m])
+            ex.skip[m] = _ptr(skip[m])
+        ex.trim_strictness = trim_strictness
+        ex.trim_target_length = trim_target_length
+        self._keep = (r1, r1_off, r2, r2_off, segment, qual, skip)
+        _check(hip_lib().nimble_call_ex(self.h, C.byref(params), _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+                                        fixed_len, max_len, mem, C.byref(ex)))
+        self.n = n
+
+    def histogram_seg(self):
+        """[(segment, class R1, class R2, count, representative read)] sorted by (segment, c1, c2)."""
+        ne = C.c_uint64()
+        _check(hip_lib().nimble_histogram_seg(self.h, None, None, None, None, None, 0, C.byref(ne)))
+        k = ne.value
+        sg, c1, c2 = (np.zeros(max(k, 1), dtype=np.uint32) for _ in range(3))
+        cnt = np.zeros(max(k, 1), dtype=np.uint64)
+        rep = np.zeros(max(k, 1), dtype=np.uint32)
+        if k:
+            _check(hip_lib().nimble_histogram_seg(self.h, sg.ctypes.data, c1.ctypes.data, c2.ctypes.data,
+                                                  cnt.ctypes.data, rep.ctypes.data, k, C.byref(ne)))
+        return [(int(sg[i]), int(c1[i]), int(c2[i]), int(cnt[i]), int(rep[i])) for i in range(k)]
+
+    def read_align_len(self, mate=0):
+        out = np.zeros(max(self.n, 1), dtype=np.uint32)
+        _check(hip_lib().nimble_read_align_len(self.h, mate, out.ctypes.data, self.n))
+        return out[:self.n]
+
     def stream_begin(self, params, paired, max_len, capacity_hint=0):
         """nimble_stream_begin: open one call whose reads arrive in batches."""
         _check(hip_lib().nimble_stream_begin(self.h, C.byref(params), int(bool(paired)), max_len, capacity_hint))
@@ -326,7 +386,8 @@ HOST_SYMBOLS = [
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
-    "nimble_library_ctx_slot", "nimble_host_read_fastq_batched", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
+    "nimble_library_ctx_slot", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
+    "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
 ]
 
 
@@ -380,6 +441,17 @@ def host_lib():
         L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
         L.nimble_library_ctx_slot.argtypes = [vp, i32]
         L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
+        L.nimble_score_call_umis.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(UmiExtra), i32,
+                                             C.POINTER(vp)]
+        L.nimble_umi_rows_free.argtypes = [vp]
+        L.nimble_umi_rows_free.restype = None
+        L.nimble_umi_rows_count.argtypes = [vp]
+        L.nimble_umi_rows_count.restype = u64
+        L.nimble_umi_rows_get.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]
+        L.nimble_umi_rows_get.restype = cp
+        L.nimble_umi_rows_reads.argtypes = [vp]
+        L.nimble_umi_rows_reads.restype = u64
+        L.nimble_umi_rows_filter.argtypes = [vp, u64, C.POINTER(i32 * 5)]
         L.nimble_host_read_fastq_batched.argtypes = [cp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32),
                                                      C.POINTER(u64), C.POINTER(u64)]
         L.nimble_score_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
@@ -619,6 +691,45 @@ class Library:
         h = C.c_void_p()
         _hcheck(host_lib().nimble_score_call_end(self.h, slot, C.byref(h)))
         return RowsHandle(h) if raw else _rows(h)
+
+    def score_call_umis(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST,
+                        segment=None, n_segments=0, qual=(None, None), skip=(None, None), per_read=False):
+        """The BAM pipeline's per-UMI score::call for a whole batch of UMI groups in one device call.
+        Returns (rows, filters): rows = [(segment, features, count, representative read)] sorted by (segment,
+        callset); filters = int32 array [n, 5] = (r1 reason, r1 score, r2 reason, r2 score, triage) or None."""
+        if r1_off is not None and n is None:
+            n = int(len(r1_off) - 1)
+        if max_len == 0 and r1_off is not None and isinstance(r1_off, np.ndarray) and n:
+            max_len = int(np.diff(r1_off.astype(np.int64)).max())
+            if r2_off is not None:
+                max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()))
+        ex = UmiExtra()
+        ex.segment = _ptr(segment)
+        ex.n_segments = n_segments
+        for m in range(2):
+            ex.qual[m] = _ptr(qual[m])
+            ex.skip[m] = _ptr(skip[m])
+        h = C.c_void_p()
+        L = host_lib()
+        _hcheck(L.nimble_score_call_umis(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+                                         max(max_len or fixed_len, 1), mem, C.byref(ex), int(per_read), C.byref(h)))
+        try:
+            rows = []
+            for i in range(L.nimble_umi_rows_count(h)):
+                sg, cnt, rep = C.c_uint32(), C.c_int32(), C.c_uint32()
+                f = L.nimble_umi_rows_get(h, i, C.byref(sg), C.byref(cnt), C.byref(rep)).decode()
+                rows.append((sg.value, f.split("\t"), cnt.value, rep.value))
+            filt = None
+            if per_read:
+                m = L.nimble_umi_rows_reads(h)
+                filt = np.zeros((m, 5), dtype=np.int32)
+                buf = (C.c_int32 * 5)()
+                for i in range(m):
+                    L.nimble_umi_rows_filter(h, i, C.byref(buf))
+                    filt[i] = buf[:]
+            return rows, filt
+        finally:
+            L.nimble_umi_rows_free(h)
 
     def stream_begin(self, paired, max_len, capacity_hint=0):
         """score::call over reads that arrive in batches (one call: dedup over everything appended)."""

@@ -120,7 +120,12 @@ struct nimble_ctx {
   DevBuf b_min_cov;
   double min_cov_percent = -1.0;
   uint32_t min_cov_len = 0;
-  DevBuf b_out_c1, b_out_c2, b_out_cnt;
+  DevBuf b_out_c1, b_out_c2, b_out_cnt, b_out_seg, b_out_rep;
+  // BAM-mode extras (nimble_call_ex)
+  DevBuf b_seg, b_alen[2], b_skip[2], b_qual[2], b_trim_ls, b_trim_qp, b_hist_rep;
+  double trim_strictness = -1.0;
+  uint64_t trim_target = ~0ULL;
+  std::vector<uint32_t> h_seg, h_rep;
   uint64_t scratch_cap = 0;
   uint64_t hist_slots = 0;
   hipEvent_t ev[7] = {};
@@ -148,7 +153,8 @@ struct nimble_ctx {
                       &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
                       &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
-                      &b_out_cnt, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
+                      &b_out_cnt, &b_out_seg, &b_out_rep, &b_seg, &b_alen[0], &b_alen[1], &b_skip[0], &b_skip[1], &b_qual[0],
+                      &b_qual[1], &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
                       &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
       b->release();
     if (h2d_stream) {
@@ -198,6 +204,41 @@ int ensure_plog(nimble_ctx *c, uint32_t max_len) {
   return NIMBLE_OK;
 }
 
+// maxinfo's two integer tables (align.rs:873-897): length scores [1000] and quality scores [61], normalised to
+// i64 exactly as the reference does (f64 arithmetic of the host libm, saturating cast); the device only adds them
+int ensure_trim_tables(nimble_ctx *c, uint64_t target_length, double strictness) {
+  if (c->b_trim_ls.p && c->trim_target == target_length && c->trim_strictness == strictness) return NIMBLE_OK;
+  const size_t LONGEST_READ = 1000, MAXQUAL = 60;
+  std::vector<double> ls(LONGEST_READ), qp(MAXQUAL + 1);
+  for (size_t i = 0; i < LONGEST_READ; ++i) {
+    const double pow1 = std::exp((double)target_length - (double)i - 1.0);
+    ls[i] = std::log(1.0 / (1.0 + pow1)) + std::log((double)(i + 1)) * (1.0 - strictness);
+  }
+  for (size_t i = 0; i <= MAXQUAL; ++i)
+    qp[i] = std::log(1.0 - std::pow(10.0, -((0.5 + (double)i) / 10.0))) * strictness;
+  auto norm_ratio = [](const std::vector<double> &a, size_t margin) {
+    double mx = std::fabs(a[0]);
+    for (size_t i = 1; i < a.size(); ++i) mx = std::max(mx, std::fabs(a[i]));
+    return (double)INT64_MAX / (mx * (double)margin);
+  };
+  auto as_i64 = [](double v) -> int64_t {  // Rust `as i64`: saturating, NaN -> 0
+    if (std::isnan(v)) return 0;
+    if (v >= 9223372036854775807.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)v;
+  };
+  const double ratio = std::max(norm_ratio(ls, LONGEST_READ * 2), norm_ratio(qp, LONGEST_READ * 2));
+  std::vector<int64_t> lsi(LONGEST_READ), qpi(MAXQUAL + 1);
+  for (size_t i = 0; i < LONGEST_READ; ++i) lsi[i] = as_i64(ls[i] * ratio);
+  for (size_t i = 0; i <= MAXQUAL; ++i) qpi[i] = as_i64(qp[i] * ratio);
+  int rc = upload(c->b_trim_ls, lsi, &c->bytes);
+  if (!rc) rc = upload(c->b_trim_qp, qpi, &c->bytes);
+  if (rc) return rc;
+  c->trim_target = target_length;
+  c->trim_strictness = strictness;
+  return NIMBLE_OK;
+}
+
 // min_cov[L] = smallest integer score s with (double)s / (double)L >= score_percent, evaluated with the
 // host's IEEE division -- the device then decides `normalized_score >= score_percent` (filter/align.rs:16)
 // with one integer compare, bit-exact
@@ -243,10 +284,12 @@ int enqueue_compact(nimble_ctx *c) {
   int rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_c2.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_cnt.ensure(slots * 8, &c->bytes);
+  if (!rc) rc = c->b_out_seg.ensure(slots * 4, &c->bytes);
+  if (!rc) rc = c->b_out_rep.ensure(slots * 4, &c->bytes);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, c->stream));
   launch_hist_compact(c->stream, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(),
-                      c->b_out_cnt.as<uint64_t>(), slots);
+                      c->b_out_cnt.as<uint64_t>(), slots, c->b_out_seg.as<uint32_t>(), c->b_out_rep.as<uint32_t>());
   return NIMBLE_OK;
 }
 
@@ -260,6 +303,7 @@ int enqueue_head(nimble_ctx *c) {
   c->dedup_clean_slots = 0;
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+  if (cb.hist_rep) HIPCHK(hipMemsetAsync(cb.hist_rep, 0, c->hist_slots * 4, s));
   if (!cb.paired) HIPCHK(hipMemsetAsync(cb.len[1], 0, nn * 4, s));
   HIPCHK(hipEventRecord(c->ev[0], s));
   return NIMBLE_OK;
@@ -305,6 +349,7 @@ int redo_dedup_count(nimble_ctx *c) {
   HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
+  if (c->cb.hist_rep) HIPCHK(hipMemsetAsync(c->cb.hist_rep, 0, c->hist_slots * 4, s));
   HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 10, 0, 8, s));
   HIPCHK(hipEventRecord(c->ev[3], s));
   launch_dedup(s, c->prm, c->cb);
@@ -364,6 +409,11 @@ int finish_call(nimble_ctx *c) {
       c->cb.hist_keys = c->b_hist_keys.as<uint64_t>();
       c->cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
       c->cb.hist_mask = c->hist_slots - 1;
+      if (c->cb.hist_rep) {
+        rc = c->b_hist_rep.ensure(c->hist_slots * 4, &c->bytes);
+        if (rc) return rc;
+        c->cb.hist_rep = c->b_hist_rep.as<uint32_t>();
+      }
       rc = redo_dedup_count(c);
       if (rc) return rc;
       continue;
@@ -377,22 +427,30 @@ int finish_call(nimble_ctx *c) {
     c->h_c1.resize(ne);
     c->h_c2.resize(ne);
     c->h_cnt.resize(ne);
+    c->h_seg.resize(ne);
+    c->h_rep.resize(ne);
     if (ne) {
-      std::vector<uint32_t> a(ne), b(ne);
+      std::vector<uint32_t> a(ne), b(ne), sg(ne), rp(ne);
       std::vector<uint64_t> k(ne);
       HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipMemcpyAsync(sg.data(), c->b_out_seg.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipMemcpyAsync(rp.data(), c->b_out_rep.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(hipStreamSynchronize(c->copy_stream));
       std::vector<uint64_t> order(ne);
       for (uint64_t i = 0; i < ne; ++i) order[i] = ((uint64_t)a[i] << 32) | b[i];
       std::vector<uint32_t> idx(ne);
       for (uint64_t i = 0; i < ne; ++i) idx[i] = (uint32_t)i;
-      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return order[x] < order[y]; });
+      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+        return sg[x] != sg[y] ? sg[x] < sg[y] : order[x] < order[y];
+      });
       for (uint64_t i = 0; i < ne; ++i) {
         c->h_c1[i] = a[idx[i]];
         c->h_c2[i] = b[idx[i]];
         c->h_cnt[i] = k[idx[i]];
+        c->h_seg[i] = sg[idx[i]];
+        c->h_rep[i] = rp[idx[i]];
       }
     }
   }
@@ -757,6 +815,13 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
     cb.dyn_hash[m] = c->b_dyn_hash[m].as<uint64_t>();
     cb.dyn_pos[m] = c->b_dyn_pos[m].as<uint32_t>();
   }
+  for (int m = 0; m < 2; ++m) {
+    cb.alen[m] = cb.len[m];  // aligned length == read length unless nimble_call_ex trims for quality
+    cb.skip[m] = nullptr;
+  }
+  cb.seg = nullptr;
+  cb.cls_bits = 0;
+  cb.hist_rep = nullptr;
   cb.min_cov = c->b_min_cov.as<uint32_t>();
   cb.scratch = c->b_scratch.as<uint32_t>();
   cb.scratch_cap = (uint32_t)c->scratch_cap;
@@ -798,6 +863,85 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc) return rc;
   // classes are a function of the dedup key when the key fixes where R1 ends: single-end, or fixed-length mates
   c->cb.fuse_count = (!r2 || !r1_off) ? 1u : 0u;
+  c->skip_pack = false;
+  return start_call(c);
+}
+
+int nimble_call_ex(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
+                   const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                   const nimble_call_extra *ex) {
+  if (!ex) return nimble_call(c, p, r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call_ex: NULL argument");
+  int rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  if (!r2 && (ex->qual[1] || ex->skip[1])) return fail(NIMBLE_E_INVALID, "nimble_call_ex: mate extras without mates");
+  HIPCHK(hipSetDevice(c->ix->device));
+  rc = stage_inputs(c, r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc) return rc;
+  rc = setup_call(c, p, n, r2 != nullptr, max_len, nullptr);
+  if (rc) return rc;
+  CallBuffers &cb = c->cb;
+  const size_t nn = std::max<uint64_t>(n, 1);
+  const bool host = mem == NIMBLE_MEM_HOST;
+  auto stage = [&](DevBuf &b, const void *src, size_t bytes, const void *&dev) -> int {
+    if (!host) {
+      dev = src;
+      return NIMBLE_OK;
+    }
+    int r = b.ensure(std::max<size_t>(bytes, 16), &c->bytes);
+    if (r) return r;
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    dev = b.p;
+    return NIMBLE_OK;
+  };
+  // dedup / count scope per read
+  if (ex->segment) {
+    uint64_t nseg = ex->n_segments;
+    if (nseg == 0) {
+      if (!host) return fail(NIMBLE_E_INVALID, "nimble_call_ex: n_segments is required for device-resident segment ids");
+      for (uint64_t i = 0; i < n; ++i) nseg = std::max<uint64_t>(nseg, (uint64_t)ex->segment[i] + 1);
+    }
+    uint32_t b = 1;
+    while (b < 32 && (1ULL << b) <= (uint64_t)c->ix->dev.cls_cap) ++b;  // ids + 1 fit in b bits
+    if (2 * b >= 64 || nseg >= (1ULL << (64 - 2 * b)))
+      return fail(NIMBLE_E_OVERFLOW, "nimble_call_ex: too many segments for one call (split the batch)");
+    const void *dev = nullptr;
+    rc = stage(c->b_seg, ex->segment, n * 4, dev);
+    if (rc) return rc;
+    cb.seg = (const uint32_t *)dev;
+    cb.cls_bits = b;
+  }
+  rc = c->b_hist_rep.ensure(c->hist_slots * 4, &c->bytes);
+  if (rc) return rc;
+  cb.hist_rep = c->b_hist_rep.as<uint32_t>();
+  // SKIP_ALIGN dummies
+  for (int m = 0; m < (r2 ? 2 : 1); ++m)
+    if (ex->skip[m]) {
+      const void *dev = nullptr;
+      rc = stage(c->b_skip[m], ex->skip[m], n, dev);
+      if (rc) return rc;
+      cb.skip[m] = (const uint8_t *)dev;
+    }
+  // quality trim: aligned length per mate from the quality strings (same layout as the bases)
+  bool trimmed = false;
+  for (int m = 0; m < (r2 ? 2 : 1); ++m)
+    if (ex->qual[m]) {
+      rc = ensure_trim_tables(c, ex->trim_target_length, ex->trim_strictness);
+      if (rc) return rc;
+      const uint64_t *off_h = m ? r2_off : r1_off;
+      const uint64_t bytes = !host ? 0 : (off_h ? off_h[n] : n * (uint64_t)fixed_len);
+      const void *dev = nullptr;
+      rc = stage(c->b_qual[m], ex->qual[m], bytes, dev);
+      if (rc) return rc;
+      rc = c->b_alen[m].ensure(nn * 4, &c->bytes);
+      if (rc) return rc;
+      launch_maxinfo(c->stream, (const uint8_t *)dev, c->in_off[m], fixed_len, n, c->b_trim_ls.as<int64_t>(),
+                     c->b_trim_qp.as<int64_t>(), c->b_alen[m].as<uint32_t>());
+      cb.alen[m] = c->b_alen[m].as<uint32_t>();
+      trimmed = true;
+    }
+  // classes are a function of the dedup key only when nothing but the key decides what is aligned
+  cb.fuse_count = (!trimmed && !ex->skip[0] && !ex->skip[1] && (!r2 || !r1_off)) ? 1u : 0u;
   c->skip_pack = false;
   return start_call(c);
 }
@@ -1075,12 +1219,48 @@ int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint
   return NIMBLE_OK;
 }
 
+int nimble_histogram_seg(nimble_ctx *c, uint32_t *segment, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count,
+                         uint32_t *representative, uint64_t cap, uint64_t *n_entries) {
+  if (!c || !n_entries) return fail(NIMBLE_E_INVALID, "nimble_histogram_seg: NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram_seg: no call has been made on this context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  const uint64_t ne = c->h_cnt.size();
+  *n_entries = ne;
+  if (cap == 0 || ne == 0) return NIMBLE_OK;
+  const uint64_t m = std::min(ne, cap);
+  if (segment) memcpy(segment, c->h_seg.data(), m * 4);
+  if (class_r1) memcpy(class_r1, c->h_c1.data(), m * 4);
+  if (class_r2) memcpy(class_r2, c->h_c2.data(), m * 4);
+  if (count) memcpy(count, c->h_cnt.data(), m * 8);
+  if (representative) memcpy(representative, c->h_rep.data(), m * 4);
+  return NIMBLE_OK;
+}
+
+int nimble_read_align_len(nimble_ctx *c, int mate, uint32_t *align_len, uint64_t n) {
+  if (!c || !align_len) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: NULL argument");
+  if (!c->called || n != c->cb.n) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: n does not match the last call");
+  if (mate < 0 || mate > 1) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: mate must be 0 or 1");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  if (n == 0) return NIMBLE_OK;
+  if (mate == 1 && !c->cb.paired) {
+    memset(align_len, 0, n * 4);
+    return NIMBLE_OK;
+  }
+  HIPCHK(hipMemcpy(align_len, c->cb.alen[mate], n * 4, hipMemcpyDeviceToHost));
+  return NIMBLE_OK;
+}
+
 int nimble_histogram_dense_se(nimble_ctx *c, int64_t *counts_dev, uint32_t n_classes) {
   if (!c || !counts_dev) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: NULL argument");
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: no call has been made");
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = finish_count_stage(c);
   if (rc) return rc;
+  if (c->cb.cls_bits) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: the last call was segmented");
   HIPCHK(hipMemsetAsync(counts_dev, 0, (size_t)n_classes * 8, c->stream));
   launch_hist_dense_se(c->stream, c->cb, counts_dev, n_classes);
   HIPCHK(hipGetLastError());

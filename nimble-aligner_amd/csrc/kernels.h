@@ -45,7 +45,12 @@ struct CallBuffers {
   uint32_t key_words;   // words per packed key (R1 ++ R2)
   uint32_t paired;
   uint64_t *keys;       // [key_words][n]
-  uint32_t *len[2];     // bases per mate
+  uint32_t *len[2];     // bases per mate (the dedup key)
+  uint32_t *alen[2];    // bases per mate that are aligned: == len unless the call trims for quality (BAM mode)
+  const uint8_t *skip[2];   // per mate, may be NULL: SKIP_ALIGN dummies (align.rs:527-528)
+  const uint32_t *seg;      // may be NULL: dedup / count scope per read (one UMI = one score::call)
+  uint32_t cls_bits;        // segmented histogram key = seg << 2b | (c1+1) << b | (c2+1); 0 = c1 << 32 | c2
+  uint32_t *hist_rep;       // may be NULL: largest read index counted into each histogram entry
   uint64_t *key_hash;   // hash of (total length, packed words)
   uint8_t *pre[2];      // prefilter verdict per mate: ShortRead / HighEntropy / R_TODO
   const uint32_t *min_cov;  // [len] -> smallest score with score/len >= score_percent in IEEE double
@@ -87,7 +92,11 @@ void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb);
 void launch_count(hipStream_t s, const CallBuffers &cb);
 void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt,
-                         uint64_t cap);
+                         uint64_t cap, uint32_t *seg = nullptr, uint32_t *rep = nullptr);
+// trim_sequence / maxinfo (align.rs:866-942): aligned length per read from the quality string and the two
+// host-built integer tables (length scores [1000], quality scores [61])
+void launch_maxinfo(hipStream_t s, const uint8_t *qual, const uint64_t *off, uint32_t fixed_len, uint64_t n,
+                    const int64_t *length_scores, const int64_t *qual_probs, uint32_t *out);
 void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes);
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
 

@@ -186,17 +186,41 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     const uint64_t phi = (acc >> 1) & 0x5555555555555555ULL, plo = acc & 0x5555555555555555ULL;
     const uint32_t tT = nT + (uint32_t)__popcll(phi & plo), tG = nG + (uint32_t)__popcll(phi & ~plo);
     const uint32_t tC = nC + (uint32_t)__popcll(~phi & plo & ((nb ? (1ULL << (2u * nb)) : 1ULL) - 1ULL));
-    const uint32_t cT = tT - pT, cG = tG - pG, cC = tC - pC;
-    const uint32_t cA = len - cT - cG - cC;
+    uint32_t cT = tT - pT, cG = tG - pG, cC = tC - pC;
     pT = tT;
     pG = tG;
     pC = tC;
+    uint32_t alen = len;
+    if (cb.alen[m] != cb.len[m]) {
+      // quality-trimmed call: the prefilters see the first alen bases only (pseudoalign gets the trimmed read,
+      // align.rs:519-523); recount over that prefix
+      alen = cb.alen[m][r];
+      alen = alen < len ? alen : len;
+      cb.alen[m][r] = alen;
+      cT = cG = cC = 0;
+      uint32_t pv = q[0], ii = 0;
+      for (uint32_t d0 = 0; d0 < alen; d0 += 4) {
+        const uint32_t nx = q[++ii];
+        const uint32_t raw = __builtin_amdgcn_alignbyte(nx, pv, mis);
+        pv = nx;
+        uint32_t c8 = conv4(raw);                       // first base in the highest pair
+        const uint32_t k = alen - d0 < 4u ? alen - d0 : 4u;
+        c8 >>= 2u * (4u - k);                           // keep the first k bases
+        const uint32_t hi = (c8 >> 1) & 0x55u, lo = c8 & 0x55u;
+        cT += (uint32_t)__popc(hi & lo);
+        cG += (uint32_t)__popc(hi & ~lo);
+        cC += (uint32_t)__popc(~hi & lo & ((1u << (2u * k)) - 1u));
+      }
+    }
+    const uint32_t cA = alen - cT - cG - cC;
     uint8_t verdict = (uint8_t)R_TODO;
-    if (len < min_len) {
+    if (cb.skip[m] && cb.skip[m][r]) {
+      verdict = NIMBLE_R_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY;
+    } else if (alen < min_len) {
       verdict = NIMBLE_R_SHORT_READ;
     } else {
       // shannon_entropy: sum f*log2(f) over A, T, C, G in that order, terms from the host-built table
-      const double *row = plog + ((uint64_t)len * (len + 1)) / 2;
+      const double *row = plog + ((uint64_t)alen * (alen + 1)) / 2;
       double e = 0.0;
       if (cA) e += row[cA];
       if (cT) e += row[cT];
@@ -751,9 +775,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
     uint64_t seedv = ~0ULL;
     if (r_own < n) {
-      const uint32_t l0 = cb.len[0][r_own];
+      const uint32_t k0 = cb.len[0][r_own];
       const uint32_t l1 = nm == 2 ? cb.len[1][r_own] : 0u;
-      const uint32_t nw = (l0 + l1 + 31u) >> 5;
+      const uint32_t nw = (k0 + l1 + 31u) >> 5;
+      const uint32_t l0 = cb.alen[0][r_own];  // bases of mate 0 that are aligned
       for (uint32_t w = 0; w < kw; ++w)
         col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
       col[kw * ALIGN_BLOCK] = 0ULL;
@@ -800,10 +825,14 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
     const bool active = r < n;
     ln.rd = lds64 + slot;
     const uint64_t pre_seed = s_seed[slot];
-    uint32_t L[2] = {0, 0};
+    uint32_t L[2] = {0, 0};   // aligned bases per mate
+    uint32_t mate1_at = 0;    // where mate 1 starts inside the key (the untrimmed length of mate 0)
     if (active) {
-      L[0] = cb.len[0][r];
-      if (nm == 2) L[1] = cb.len[1][r];
+      L[0] = cb.alen[0][r];
+      if (nm == 2) {
+        L[1] = cb.alen[1][r];
+        mate1_at = cb.len[0][r];
+      }
     }
     bool any_walk = false;
     for (int m = 0; m < nm; ++m) {
@@ -822,7 +851,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
         } else {
           uint32_t cov = 0, mis = 0;
           const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
-          bool some = walk(ix, ln, m ? L[0] : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed);
+          bool some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed);
           if (!some) {
             reason = NIMBLE_R_NO_MATCH;
           } else {
@@ -985,9 +1014,15 @@ __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
   else atomicAdd((unsigned long long *)&cb.state[9], 1ULL);  // tag collision: next round probes further
 }
 
-// one unique read key adds 1 to the (class R1, class R2) histogram (open addressing over u64 keys)
-__device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t c1, uint32_t c2) {
-  const uint64_t key = ((uint64_t)c1 << 32) | c2;
+// one unique read key adds 1 to the (segment, class R1, class R2) histogram (open addressing over u64 keys)
+__device__ __forceinline__ uint64_t hist_key(const CallBuffers &cb, uint32_t seg, uint32_t c1, uint32_t c2) {
+  if (cb.cls_bits == 0) return ((uint64_t)c1 << 32) | c2;
+  const uint32_t b = cb.cls_bits;  // CLS_NONE + 1 wraps to 0
+  return ((uint64_t)seg << (2u * b)) | ((uint64_t)(uint32_t)(c1 + 1u) << b) | (uint64_t)(uint32_t)(c2 + 1u);
+}
+
+__device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t seg, uint32_t c1, uint32_t c2, uint32_t read) {
+  const uint64_t key = hist_key(cb, seg, c1, c2);
   uint64_t pos = mix64(key) & cb.hist_mask;
   for (uint64_t probes = 0; probes <= cb.hist_mask; ++probes) {
     uint64_t cur = cb.hist_keys[pos];  // almost always already present: skip the CAS
@@ -995,6 +1030,7 @@ __device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t c1, uin
       cur = atomicCAS((unsigned long long *)&cb.hist_keys[pos], (unsigned long long)HIST_EMPTY, (unsigned long long)key);
     if (cur == HIST_EMPTY || cur == key) {
       atomicAdd((unsigned long long *)&cb.hist_cnt[pos], 1ULL);
+      if (cb.hist_rep) atomicMax(&cb.hist_rep[pos], read);
       return;
     }
     pos = (pos + 1) & cb.hist_mask;
@@ -1025,7 +1061,9 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
     cb.slot[i] = SLOT_NONE;
     return;
   }
-  const uint64_t h = cb.key_hash[i];
+  // the dedup scope is the segment (one UMI = one score::call): it is part of the key
+  const uint32_t seg = cb.seg ? cb.seg[i] : 0u;
+  const uint64_t h = cb.seg ? mix64(cb.key_hash[i] ^ ((uint64_t)seg * 0x9E3779B97F4A7C15ULL)) : cb.key_hash[i];
   const uint32_t tag = (uint32_t)(h >> 32) | 1u;
   const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)i;
   const uint32_t total = cb.len[0][i] + (cb.paired ? cb.len[1][i] : 0u);
@@ -1036,12 +1074,12 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
     if (cur == 0) {
       // first copy of this key.  When the classes are a function of the key alone (single-end, or mates of one
       // fixed length) any copy may stand for the key in the histogram, so count it here and skip k_count.
-      if (cb.fuse_count) hist_add(cb, c1, c2);
+      if (cb.fuse_count) hist_add(cb, seg, c1, c2, (uint32_t)i);
       break;
     }
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t j = (uint32_t)cur;
-      bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total;
+      bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total && (!cb.seg || cb.seg[j] == seg);
       for (uint32_t w = 0; same && w < nw; ++w) same = cb.keys[(uint64_t)w * cb.key_stride + i] == cb.keys[(uint64_t)w * cb.key_stride + j];
       if (same) {
         atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
@@ -1063,20 +1101,61 @@ __global__ void k_count(CallBuffers cb) {
   if ((uint32_t)cb.dedup[s] != (uint32_t)i) return;
   cb.counted[i] = 1;
   if (cb.fuse_count) return;
-  hist_add(cb, cb.cls[0][i], cb.paired ? cb.cls[1][i] : CLS_NONE);
+  hist_add(cb, cb.seg ? cb.seg[i] : 0u, cb.cls[0][i], cb.paired ? cb.cls[1][i] : CLS_NONE, (uint32_t)i);
 }
 
-__global__ void k_hist_compact(CallBuffers cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt, uint64_t cap) {
+__global__ void k_hist_compact(CallBuffers cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt, uint64_t cap, uint32_t *seg,
+                               uint32_t *rep) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > cb.hist_mask) return;
   const uint64_t key = cb.hist_keys[i];
   if (key == HIST_EMPTY) return;
   uint64_t o = atomicAdd((unsigned long long *)&cb.state[11], 1ULL);
   if (o < cap) {
-    c1[o] = (uint32_t)(key >> 32);
-    c2[o] = (uint32_t)key;
+    if (cb.cls_bits == 0) {
+      c1[o] = (uint32_t)(key >> 32);
+      c2[o] = (uint32_t)key;
+      if (seg) seg[o] = 0;
+    } else {
+      const uint32_t b = cb.cls_bits;
+      const uint64_t m = (1ULL << b) - 1ULL;
+      c1[o] = (uint32_t)((key >> b) & m) - 1u;  // 0 wraps back to CLS_NONE
+      c2[o] = (uint32_t)(key & m) - 1u;
+      if (seg) seg[o] = (uint32_t)(key >> (2u * b));
+    }
     cnt[o] = cb.hist_cnt[i];
+    if (rep) rep[o] = cb.hist_rep ? cb.hist_rep[i] : 0u;
   }
+}
+
+// trim_sequence / maxinfo (align.rs:866-942): the number of leading bases that are aligned, from the quality
+// string.  Integer scores from two host-built tables; the running best is compared as f64, as the reference does.
+__global__ void k_maxinfo(const uint8_t *__restrict__ qual, const uint64_t *__restrict__ off, uint32_t fixed_len,
+                          uint64_t n, const int64_t *__restrict__ length_scores, const int64_t *__restrict__ qual_probs,
+                          uint32_t *__restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t s = off ? off[r] : r * fixed_len;
+  const uint32_t len = off ? (uint32_t)(off[r + 1] - s) : fixed_len;
+  const uint8_t *q = qual + s;
+  int64_t accum = 0;
+  double max_score = -1.7976931348623157e308;  // f64::MIN
+  uint32_t pos = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t c = q[i];
+    c = c > 60u ? 60u : c;                     // MAXQUAL; the raw byte, not Phred (align.rs:905-906)
+    accum += qual_probs[c];
+    const int64_t score = (i < 1000u ? length_scores[i] : 0) + accum;
+    const double sf = (double)score;
+    if (sf >= max_score) {
+      max_score = sf;
+      pos = i + 1;
+    }
+  }
+  uint32_t t;
+  if (pos < 1 || max_score == 0.0) t = 0;
+  else t = pos < len ? pos : len;
+  out[r] = t;
 }
 
 __global__ void k_hist_dense_se(CallBuffers cb, int64_t *counts, uint32_t n_classes) {
@@ -1164,8 +1243,15 @@ void launch_count(hipStream_t s, const CallBuffers &cb) {
   hipLaunchKernelGGL(k_count, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, cb);
 }
 void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt,
-                         uint64_t cap) {
-  hipLaunchKernelGGL(k_hist_compact, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, c1, c2, cnt, cap);
+                         uint64_t cap, uint32_t *seg, uint32_t *rep) {
+  hipLaunchKernelGGL(k_hist_compact, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, c1, c2, cnt, cap,
+                     seg, rep);
+}
+void launch_maxinfo(hipStream_t s, const uint8_t *qual, const uint64_t *off, uint32_t fixed_len, uint64_t n,
+                    const int64_t *length_scores, const int64_t *qual_probs, uint32_t *out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_maxinfo, dim3(blocks_for(n, 256)), dim3(256), 0, s, qual, off, fixed_len, n, length_scores,
+                     qual_probs, out);
 }
 void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes) {
   hipLaunchKernelGGL(k_hist_dense_se, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, counts,

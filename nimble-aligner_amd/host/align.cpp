@@ -307,6 +307,7 @@ struct PseudoAligner::CoercionMemo {
   std::unique_ptr<Coercer> coercer;
   // (class R1 << 32 | class R2) -> index into `callsets` (or -1 when the pair is triaged away)
   std::unordered_map<uint64_t, int32_t> pairs;
+  std::unordered_map<uint64_t, FilterReason> pair_triage;  // why a pair with id -1 was dropped (align.rs:228-239,776)
   std::vector<std::vector<std::string>> callsets;
   std::map<std::vector<std::string>, int32_t> callset_ids;
   std::vector<int32_t> sorted;  // callset ids in Vec<String> order; rebuilt when callsets grew
@@ -490,6 +491,7 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
         }
         id = ins.first->second;
       }
+      if (id < 0) memo.pair_triage[key] = triage;
       it = memo.pairs.emplace(key, id).first;
     }
     if (it->second >= 0) memo.counts[(size_t)it->second] += (int64_t)cnt[e];
@@ -526,6 +528,118 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
       fr.score1 = fr.r1 == FilterReason::SuccessfulMatch ? (size_t)s[0][i] : 0;
       fr.score2 = fr.r2 == FilterReason::SuccessfulMatch ? (size_t)s[1][i] : 0;
       fr.triage = FilterReason::None;
+    }
+  }
+  return out;
+}
+
+// The BAM pipeline's calls (process/bam.rs:183-226,229-290): one score::call per UMI group, here all groups
+// of a batch in ONE device call (segment ids scope the dedup and the counts), reads trimmed for quality on the
+// device, SKIP_ALIGN dummies skipped.  Rows come back per segment, sorted by (segment, callset).
+UmiOutput get_calls_umis(const ReadBatch &seqs, const ReadBatch *mates, const UmiExtras &ex, PseudoAligner &index,
+                         const reference_library::Reference &reference, const AlignFilterConfig &config,
+                         bool want_per_read) {
+  if (mates && mates->n != seqs.n)
+    throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  nimble_align_params p = make_params(config);
+  uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
+  if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
+  nimble_call_extra x;
+  memset(&x, 0, sizeof x);
+  x.segment = ex.segment;
+  x.n_segments = ex.n_segments;
+  x.qual[0] = ex.qual[0];
+  x.qual[1] = ex.qual[1];
+  x.skip[0] = ex.skip[0];
+  x.skip[1] = ex.skip[1];
+  x.trim_strictness = config.trim_strictness;
+  x.trim_target_length = config.trim_target_length;
+  nimble_ctx *ctx = index.ctx();
+  check_rc(nimble_call_ex(ctx, &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+                          mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
+                          seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST, &x),
+           "nimble_call_ex");
+  PseudoAligner::CoercionMemo &memo = index.memo_for(reference, config);
+  uint64_t ne = 0;
+  check_rc(nimble_histogram_seg(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne), "nimble_histogram_seg");
+  std::vector<uint32_t> sg(ne), c1(ne), c2(ne), rep(ne);
+  std::vector<uint64_t> cnt(ne);
+  if (ne)
+    check_rc(nimble_histogram_seg(ctx, sg.data(), c1.data(), c2.data(), cnt.data(), rep.data(), ne, &ne),
+             "nimble_histogram_seg");
+  static const std::vector<uint32_t> empty;
+  auto callset_of = [&](uint32_t a, uint32_t b) -> int32_t {
+    const uint64_t key = ((uint64_t)a << 32) | b;
+    auto it = memo.pairs.find(key);
+    if (it != memo.pairs.end()) return it->second;
+    const bool has1 = a != NIMBLE_CLASS_NONE, has2 = b != NIMBLE_CLASS_NONE;
+    FilterReason triage;
+    std::vector<std::string> callset =
+        memo.coercer->coerce(has1, has1 ? index.eq_class(a) : empty, has2, has2 ? index.eq_class(b) : empty, triage);
+    int32_t id = -1;
+    if (!callset.empty()) {
+      auto ins = memo.callset_ids.emplace(callset, (int32_t)memo.callsets.size());
+      if (ins.second) {
+        memo.callsets.push_back(std::move(callset));
+        memo.counts.push_back(0);
+        memo.sorted.clear();
+      }
+      id = ins.first->second;
+    } else {
+      memo.pair_triage[key] = triage;
+    }
+    memo.pairs.emplace(key, id);
+    return id;
+  };
+  UmiOutput out;
+  // entries arrive sorted by (segment, c1, c2): fold each segment's class pairs into callsets
+  for (uint64_t e = 0; e < ne;) {
+    const uint32_t seg = sg[e];
+    std::map<int32_t, std::pair<int64_t, uint32_t>> acc;  // callset id -> (count, representative)
+    for (; e < ne && sg[e] == seg; ++e) {
+      const int32_t id = callset_of(c1[e], c2[e]);
+      if (id < 0) continue;
+      auto &slot = acc[id];
+      slot.first += (int64_t)cnt[e];
+      slot.second = std::max(slot.second, rep[e]);
+    }
+    const size_t first = out.rows.size();
+    for (auto &kv : acc) {
+      UmiRow r;
+      r.segment = seg;
+      r.features = memo.callsets[(size_t)kv.first];
+      r.count = (int32_t)kv.second.first;
+      r.representative = kv.second.second;
+      out.rows.push_back(std::move(r));
+    }
+    std::sort(out.rows.begin() + (long)first, out.rows.end(),
+              [](const UmiRow &a, const UmiRow &b) { return a.features < b.features; });
+  }
+  if (want_per_read) {
+    const uint64_t n = seqs.n;
+    out.per_read.resize(n);
+    std::vector<int32_t> r[2], sc[2];
+    std::vector<uint32_t> cl[2];
+    for (int m = 0; m < 2; ++m) {
+      r[m].resize(n);
+      sc[m].resize(n);
+      cl[m].resize(n);
+      check_rc(nimble_read_records(ctx, m, r[m].data(), sc[m].data(), nullptr, cl[m].data(), nullptr, n),
+               "nimble_read_records");
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+      FilterRecord &fr = out.per_read[i];
+      fr.r1 = (FilterReason)r[0][i];
+      fr.r2 = (FilterReason)r[1][i];
+      fr.score1 = fr.r1 == FilterReason::SuccessfulMatch ? (size_t)sc[0][i] : 0;
+      fr.score2 = fr.r2 == FilterReason::SuccessfulMatch ? (size_t)sc[1][i] : 0;
+      fr.triage = FilterReason::None;
+      // post_triaged_keys (align.rs:228-239): reads that reached the coercion and were dropped there
+      const uint32_t a = cl[0][i], b = cl[1][i];
+      if (fr.r1 != FilterReason::NotMatchingPair && (a != NIMBLE_CLASS_NONE || b != NIMBLE_CLASS_NONE)) {
+        auto t = memo.pair_triage.find(((uint64_t)a << 32) | b);
+        if (t != memo.pair_triage.end()) fr.triage = t->second;
+      }
     }
   }
   return out;

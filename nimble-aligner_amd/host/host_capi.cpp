@@ -40,6 +40,10 @@ struct nimble_library {
   bool pending[2] = {false, false};  // nimble_score_call_begin without its _end yet
   uint64_t pending_n[2] = {0, 0};
 };
+struct nimble_umi_rows {
+  align::UmiOutput out;
+  std::vector<std::string> joined;
+};
 struct nimble_rows {
   std::vector<align::ScoreRow> rows;
   std::vector<std::string> joined;
@@ -201,6 +205,59 @@ int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
               [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
     *out = make_rows(std::move(o));
   });
+}
+
+int nimble_score_call_umis(nimble_library *l, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                           const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                           const nimble_umi_extra *extra, int want_per_read, nimble_umi_rows **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_umis: the library has no index");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    align::UmiExtras ex;
+    if (extra) {
+      ex.segment = extra->segment;
+      ex.n_segments = extra->n_segments;
+      for (int m = 0; m < 2; ++m) {
+        ex.qual[m] = extra->qual[m];
+        ex.skip[m] = extra->skip[m];
+      }
+    }
+    std::unique_ptr<nimble_umi_rows> r(new nimble_umi_rows());
+    r->out = align::get_calls_umis(b1, r2 ? &b2 : nullptr, ex, *l->index, l->ref, l->cfg, want_per_read != 0);
+    for (auto &row : r->out.rows) r->joined.push_back(join_tab(row.features));
+    *out = r.release();
+  });
+}
+void nimble_umi_rows_free(nimble_umi_rows *r) { delete r; }
+uint64_t nimble_umi_rows_count(const nimble_umi_rows *r) { return r->out.rows.size(); }
+const char *nimble_umi_rows_get(const nimble_umi_rows *r, uint64_t i, uint32_t *segment, int32_t *count,
+                                uint32_t *representative) {
+  const align::UmiRow &row = r->out.rows.at(i);
+  if (segment) *segment = row.segment;
+  if (count) *count = row.count;
+  if (representative) *representative = row.representative;
+  return r->joined.at(i).c_str();
+}
+uint64_t nimble_umi_rows_reads(const nimble_umi_rows *r) { return r->out.per_read.size(); }
+int nimble_umi_rows_filter(const nimble_umi_rows *r, uint64_t read, int32_t out[5]) {
+  if (read >= r->out.per_read.size()) return -1;
+  const align::FilterRecord &f = r->out.per_read[read];
+  out[0] = (int32_t)f.r1;
+  out[1] = (int32_t)f.score1;
+  out[2] = (int32_t)f.r2;
+  out[3] = (int32_t)f.score2;
+  out[4] = (int32_t)f.triage;
+  return 0;
 }
 
 int nimble_score_stream_begin(nimble_library *l, int paired, uint32_t max_len, uint64_t capacity_hint) {

@@ -180,6 +180,27 @@ void begin_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, Ps
 CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                      const AlignFilterConfig &config, int slot, bool want_per_read = false);
 
+// What the BAM pipeline adds to a call (process/bam.rs:229-290, align.rs:516-552); every field optional.
+struct UmiExtras {
+  const uint32_t *segment = nullptr;  // [n] UMI group per read(-pair): one score::call each
+  uint32_t n_segments = 0;            // > largest id (0 = scan, host memory only)
+  const uint8_t *qual[2] = {nullptr, nullptr};  // qualities, laid out like the bases: 3' quality trim
+  const uint8_t *skip[2] = {nullptr, nullptr};  // SKIP_ALIGN dummies
+};
+struct UmiRow {
+  uint32_t segment;
+  std::vector<std::string> features;
+  int32_t count;
+  uint32_t representative;  // a read of this callset (the reference keeps one read's BAM fields per callset)
+};
+struct UmiOutput {
+  std::vector<UmiRow> rows;           // sorted by (segment, callset)
+  std::vector<FilterRecord> per_read;  // when requested
+};
+UmiOutput get_calls_umis(const ReadBatch &sequences, const ReadBatch *mate_sequences, const UmiExtras &extras,
+                         PseudoAligner &index, const reference_library::Reference &reference,
+                         const AlignFilterConfig &config, bool want_per_read = false);
+
 // get_calls over reads that arrive in batches (one call, dedup over everything appended): the FASTQ pipeline
 // parses batch i+1 while the GPU packs and aligns batch i (include/nimble_hip.h: nimble_stream_*).
 class CallStream {

@@ -894,6 +894,16 @@ struct Result {
   std::vector<uint64_t> class_hash[2];
   std::vector<uint8_t> counted;
   uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // BAM-mode call (one score::call per UMI): segment id of every row, aligned (trimmed) length per read
+  std::vector<uint32_t> row_segment;
+  std::vector<int32_t> align_len[2];
+};
+
+// what the BAM pipeline adds per read (process/bam.rs:229-290, align.rs:516-552): quality strings for the 3' trim
+// and the SKIP_ALIGN flag of unpaired dummies; all optional
+struct UmiExtras {
+  const uint8_t *q1 = nullptr, *q2 = nullptr;   // qualities, same offsets as the bases
+  const uint8_t *skip1 = nullptr, *skip2 = nullptr;
 };
 
 struct Partial {
@@ -906,20 +916,55 @@ struct Partial {
 };
 
 // one partition of score_sequences (align.rs:475-729); `mine(i)` selects the reads of this partition
+size_t maxinfo(const std::string &quality, size_t target_length, double strictness);
+
+// align.rs:866-871 trim_sequence: the first maxinfo(quality) bases
+Dna trim_sequence(const Dna &sequence, const uint8_t *qual, size_t qlen, const ora_config &cfg, size_t &trimmed_length) {
+  trimmed_length = maxinfo(std::string((const char *)qual, qlen), (size_t)cfg.trim_target_length, cfg.trim_strictness);
+  std::string s = sequence.to_string();
+  if (trimmed_length > s.size()) throw std::runtime_error("byte index out of range in trim_sequence");
+  return Dna::from_acgt_bytes((const uint8_t *)s.data(), trimmed_length);
+}
+
 void score_sequences(const Index &ix, const ora_config &cfg, const uint8_t *r1, const uint64_t *o1,
                      const uint8_t *r2, const uint64_t *o2, uint64_t n, const std::function<bool(uint64_t)> &mine,
-                     Partial &P, Result *rec) {
-  for (uint64_t i = 0; i < n; ++i) {
-    if (!mine(i)) continue;
+                     Partial &P, Result *rec, const std::vector<uint64_t> *order = nullptr,
+                     const UmiExtras *ex = nullptr) {
+  const uint64_t count = order ? order->size() : n;
+  for (uint64_t it = 0; it < count; ++it) {
+    const uint64_t i = order ? (*order)[it] : it;
+    if (!order && !mine(i)) continue;
     Dna read = Dna::from_acgt_bytes(r1 + o1[i], (size_t)(o1[i + 1] - o1[i]));
     WalkCounters before = P.wc;
-    Alignment a1 = pseudoalign(read, ix, cfg, MIN_READ_LENGTH, P.wc);
+    // align.rs:519-529: trim for quality when there is metadata, skip the alignment of an unpaired dummy
+    size_t t1 = read.len(), t2 = 0;
+    Alignment a1;
+    if (ex && ex->skip1 && ex->skip1[i]) {
+      a1.reason = ORA_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY;
+    } else if (ex && ex->q1) {
+      Dna trimmed = trim_sequence(read, ex->q1 + o1[i], (size_t)(o1[i + 1] - o1[i]), cfg, t1);
+      a1 = pseudoalign(trimmed, ix, cfg, MIN_READ_LENGTH, P.wc);
+    } else {
+      a1 = pseudoalign(read, ix, cfg, MIN_READ_LENGTH, P.wc);
+    }
     bool have_mate = r2 != nullptr;
     Alignment a2;
     Dna mate;
     if (have_mate) {
       mate = Dna::from_acgt_bytes(r2 + o2[i], (size_t)(o2[i + 1] - o2[i]));
-      a2 = pseudoalign(mate, ix, cfg, MIN_READ_LENGTH, P.wc);
+      t2 = mate.len();
+      if (ex && ex->skip2 && ex->skip2[i]) {
+        a2.reason = ORA_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY;
+      } else if (ex && ex->q2) {
+        Dna trimmed = trim_sequence(mate, ex->q2 + o2[i], (size_t)(o2[i + 1] - o2[i]), cfg, t2);
+        a2 = pseudoalign(trimmed, ix, cfg, MIN_READ_LENGTH, P.wc);
+      } else {
+        a2 = pseudoalign(mate, ix, cfg, MIN_READ_LENGTH, P.wc);
+      }
+    }
+    if (rec && !rec->align_len[0].empty()) {
+      rec->align_len[0][i] = (int32_t)t1;
+      rec->align_len[1][i] = (int32_t)t2;
     }
     if (a1.walk_some || (have_mate && a2.walk_some)) P.seeded++;
     if (a1.reason == ORA_SHORT_READ || a1.reason == ORA_HIGH_ENTROPY) P.prefiltered++;
@@ -1050,6 +1095,59 @@ Result *call(const Index &ix, const Ref &ref, const ora_config &cfg, const uint8
     }
     res->rows.emplace_back(joined, kv.second);
   }
+  return res;
+}
+
+// The BAM pipeline's use of score::call (process/bam.rs:183-226,229-290): one call per UMI group.  `segment`
+// groups the reads (all reads of one id form one call, in input order); rows come back sorted by (segment, callset).
+Result *call_umi(const Index &ix, const Ref &ref, const ora_config &cfg, const uint8_t *r1, const uint64_t *o1,
+                 const uint8_t *r2, const uint64_t *o2, const UmiExtras &ex, const uint32_t *segment, uint64_t n,
+                 bool keep) {
+  Result *res = new Result();
+  Result *rec = nullptr;
+  if (keep) {
+    for (int m = 0; m < 2; ++m) {
+      res->reason[m].assign(n, ORA_NONE);
+      res->score[m].assign(n, 0);
+      res->mism[m].assign(n, 0);
+      res->class_hash[m].assign(n, 0);
+      res->align_len[m].assign(n, 0);
+    }
+    res->counted.assign(n, 0);
+    rec = res;
+  }
+  std::map<uint32_t, std::vector<uint64_t>> groups;
+  for (uint64_t i = 0; i < n; ++i) groups[segment ? segment[i] : 0u].push_back(i);
+  try {
+    for (auto &g : groups) {
+      Partial P;
+      score_sequences(ix, cfg, r1, o1, r2, o2, n, [](uint64_t) { return true; }, P, rec, &g.second, &ex);
+      coerce_partition(ref, cfg, P);
+      res->counters[1] += P.score_map.size();
+      res->counters[2] += P.wc.probes;
+      res->counters[3] += P.wc.nodes;
+      res->counters[4] += P.wc.class_entries;
+      res->counters[5] += P.seeded;
+      res->counters[6] += P.prefiltered;
+      res->counters[7] += P.filter_reason_keys.size();
+      if (keep)
+        for (auto &kv : P.score_map) res->counted[kv.second.rep] = 1;
+      for (auto &kv : P.results) {
+        std::string joined;
+        for (size_t i = 0; i < kv.first.size(); ++i) {
+          if (i) joined.push_back('\t');
+          joined += kv.first[i];
+        }
+        res->rows.emplace_back(joined, kv.second);
+        res->row_segment.push_back(g.first);
+      }
+    }
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    delete res;
+    return nullptr;
+  }
+  res->counters[0] = n;
   return res;
 }
 
@@ -1324,6 +1422,27 @@ ora_result *ora_call(const ora_index *ix, const ora_ref *ref, const ora_config *
   ora_result *o = new ora_result();
   o->r = r;
   return o;
+}
+ora_result *ora_call_umi(const ora_index *ix, const ora_ref *ref, const ora_config *cfg, const uint8_t *r1,
+                         const uint64_t *r1_off, const uint8_t *r2, const uint64_t *r2_off, const uint8_t *q1,
+                         const uint8_t *q2, const uint8_t *skip1, const uint8_t *skip2, const uint32_t *segment,
+                         uint64_t n, int keep_per_read) {
+  UmiExtras ex;
+  ex.q1 = q1;
+  ex.q2 = q2;
+  ex.skip1 = skip1;
+  ex.skip2 = skip2;
+  Result *r = call_umi(*ix->ix, ref->r, *cfg, r1, r1_off, r2, r2_off, ex, segment, n, keep_per_read != 0);
+  if (!r) return nullptr;
+  ora_result *o = new ora_result();
+  o->r = r;
+  return o;
+}
+uint32_t ora_result_row_segment(const ora_result *r, uint64_t i) {
+  return i < r->r->row_segment.size() ? r->r->row_segment[i] : 0u;
+}
+const int32_t *ora_result_align_len(const ora_result *r, int m) {
+  return r->r->align_len[m].empty() ? nullptr : r->r->align_len[m].data();
 }
 void ora_result_free(ora_result *r) { if (r) { delete r->r; delete r; } }
 uint64_t ora_result_n_rows(const ora_result *r) { return r->r->rows.size(); }

@@ -143,6 +143,18 @@ int ora_process_class_to_features(const ora_ref *, const ora_config *, const uin
 ora_result *ora_call(const ora_index *, const ora_ref *, const ora_config *, const uint8_t *r1,
                      const uint64_t *r1_off, const uint8_t *r2, const uint64_t *r2_off, uint64_t n,
                      int n_threads, int keep_per_read);
+/* ---- the BAM pipeline's use of score::call: one call per UMI group (src/process/bam.rs:183-226,229-290) ----
+ * segment[n] (NULL = one group): reads with the same id form one score::call, in input order.
+ * q1/q2 (NULL = no metadata): quality strings laid out like the bases (same offsets); the read is aligned after
+ *   trim_sequence (align.rs:866-871) while the dedup key stays the untrimmed read (align.rs:576-579).
+ * skip1/skip2 (NULL = none): SKIP_ALIGN dummies (align.rs:527-528,549-550).
+ * Rows are sorted by (segment, callset); ora_result_row_segment gives the segment of a row. */
+ora_result *ora_call_umi(const ora_index *, const ora_ref *, const ora_config *, const uint8_t *r1,
+                         const uint64_t *r1_off, const uint8_t *r2, const uint64_t *r2_off, const uint8_t *q1,
+                         const uint8_t *q2, const uint8_t *skip1, const uint8_t *skip2, const uint32_t *segment,
+                         uint64_t n, int keep_per_read);
+uint32_t ora_result_row_segment(const ora_result *, uint64_t i);
+const int32_t *ora_result_align_len(const ora_result *, int mate); /* bases aligned after the trim (keep_per_read) */
 void ora_result_free(ora_result *);
 uint64_t ora_result_n_rows(const ora_result *);
 /* features joined by '\t' (the TSV cell layout of utils::write_to_tsv), count */

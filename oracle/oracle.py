@@ -381,6 +381,60 @@ def call(index, ref, cfg, r1, r1_off, r2=None, r2_off=None, n_threads=1, keep_pe
         lib().ora_result_free(h)
 
 
+def call_umi(index, ref, cfg, r1, r1_off, r2=None, r2_off=None, q1=None, q2=None, skip1=None, skip2=None,
+             segment=None, keep_per_read=False):
+    """The BAM pipeline's score::call per UMI group (src/process/bam.rs:183-226,229-290): `segment` groups the
+    reads, q1/q2 are quality strings laid out like the bases (quality trim, align.rs:866-871), skip1/skip2 the
+    SKIP_ALIGN dummies.  Rows: (segment, features, count) sorted by (segment, callset)."""
+    r1 = np.ascontiguousarray(r1, dtype=np.uint8)
+    r1_off = np.ascontiguousarray(r1_off, dtype=np.uint64)
+    n = int(r1_off.size - 1)
+
+    def opt(a, dt):
+        return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+    r2, r2_off = opt(r2, np.uint8), opt(r2_off, np.uint64)
+    q1, q2, skip1, skip2 = opt(q1, np.uint8), opt(q2, np.uint8), opt(skip1, np.uint8), opt(skip2, np.uint8)
+    segment = opt(segment, np.uint32)
+    ptr = lambda a: None if a is None else a.ctypes.data
+    L = lib()
+    L.ora_call_umi.restype = C.c_void_p
+    L.ora_call_umi.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Config)] + [C.c_void_p] * 9 + [C.c_uint64, C.c_int]
+    L.ora_result_row_segment.restype = C.c_uint32
+    L.ora_result_row_segment.argtypes = [C.c_void_p, C.c_uint64]
+    L.ora_result_align_len.restype = C.POINTER(C.c_int32)
+    L.ora_result_align_len.argtypes = [C.c_void_p, C.c_int]
+    h = L.ora_call_umi(index.h, ref.h, C.byref(cfg), ptr(r1), ptr(r1_off), ptr(r2), ptr(r2_off), ptr(q1), ptr(q2),
+                       ptr(skip1), ptr(skip2), ptr(segment), n, 1 if keep_per_read else 0)
+    if not h:
+        raise _err()
+    try:
+        rows = []
+        for i in range(L.ora_result_n_rows(h)):
+            cnt = C.c_int32()
+            s = L.ora_result_row(h, i, C.byref(cnt)).decode()
+            rows.append((int(L.ora_result_row_segment(h, i)), s.split("\t"), cnt.value))
+        per_read = None
+        if keep_per_read:
+            def arr(p, dt):
+                return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+            per_read = dict(
+                reason=[arr(L.ora_result_reason(h, m), np.int32) for m in (0, 1)],
+                score=[arr(L.ora_result_score(h, m), np.int32) for m in (0, 1)],
+                mismatches=[arr(L.ora_result_mismatch(h, m), np.int32) for m in (0, 1)],
+                class_hash=[arr(L.ora_result_class_hash(h, m), np.uint64) for m in (0, 1)],
+                align_len=[arr(L.ora_result_align_len(h, m), np.int32) for m in (0, 1)],
+                counted=arr(L.ora_result_counted(h), np.uint8),
+            )
+        c = (C.c_uint64 * 8)()
+        L.ora_result_counters(h, c)
+        counters = dict(reads=c[0], unique_keys=c[1], probes=c[2], nodes=c[3], class_entries=c[4], seeded=c[5],
+                        prefiltered=c[6], filter_reason_keys=c[7])
+        return CallResult(rows, per_read, counters)
+    finally:
+        L.ora_result_free(h)
+
+
 def get_calls_fastq(index, ref, cfg, reads, mates=None, **kw):
     b1, o1 = pack_reads(reads)
     if mates is not None:

@@ -306,3 +306,42 @@ def test_natural_lexical_cmp():
     assert c("b", "B") > 0 and c("B", "b") < 0  # tie on the lexical form -> plain order
     assert c("x", "x") == 0
     assert c("A02-0", "A02-0" + SEP + "rev") < 0
+
+
+def test_call_umi_is_one_call_per_group_and_trims_before_aligning():
+    # the BAM pipeline's composition of the pinned pieces (score::call per UMI, trim_sequence, SKIP_ALIGN):
+    # no reference test reaches it without the LFS BAM files, so this checks the restatement against its parts
+    import importlib
+    synth = importlib.import_module("nimble-aligner_amd.synth")
+    names, seqs = synth.make_library(40)
+    obj = synth.library_json(names, seqs)
+    obj[0].update(trim_target_length=40, trim_strictness=0.9)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(["reference_genome", "sequence_name", "nt_length", "sequence"], cols, "")
+    cfg = ora.config_from_json(obj[0], len(names), "unstranded")
+    idx = ora.Index.from_reference(ref)
+    r1, r2 = synth.make_reads(seqs, 600, paired=True, seed=3)
+    n, L = r1.shape
+    o = synth.fixed_offsets(n, L)
+    seg = (np.arange(n) // 7).astype(np.uint32)
+    got = ora.call_umi(idx, ref, cfg, r1.reshape(-1), o, r2.reshape(-1), o, segment=seg)
+    want = []
+    for g in range(int(seg.max()) + 1):
+        sel = np.nonzero(seg == g)[0]
+        og = synth.fixed_offsets(len(sel), L)
+        res = ora.call(idx, ref, cfg, r1[sel].reshape(-1), og, r2[sel].reshape(-1), og)
+        want += [(g, f, c) for f, c in res.rows]
+    assert got.rows == want and len(want) > 50
+    # trimming: aligned length == maxinfo(quality); a read cut below 40 bases becomes ShortRead (reason 8)
+    q = np.full((n, L), ord("I"), dtype=np.uint8)
+    q[::2, 30:] = 0
+    res = ora.call_umi(idx, ref, cfg, r1.reshape(-1), o, r2.reshape(-1), o, q1=q.reshape(-1), q2=q.reshape(-1),
+                       segment=seg, keep_per_read=True)
+    al = res.per_read["align_len"][0]
+    assert al[1] == L and al[0] == ora.maxinfo(bytes(q[0]), 40, 0.9) and al[0] < 40
+    assert (res.per_read["reason"][0][::2] == 8).all()
+    # SKIP_ALIGN dummies are not aligned
+    skip = np.zeros(n, dtype=np.uint8)
+    skip[5] = 1
+    res = ora.call_umi(idx, ref, cfg, r1.reshape(-1), o, r2.reshape(-1), o, skip2=skip, keep_per_read=True)
+    assert res.per_read["reason"][1][5] == 15 and res.per_read["score"][1][5] == 0
