@@ -312,6 +312,7 @@ def test_call_umi_is_one_call_per_group_and_trims_before_aligning():
     # the BAM pipeline's composition of the pinned pieces (score::call per UMI, trim_sequence, SKIP_ALIGN):
     # no reference test reaches it without the LFS BAM files, so this checks the restatement against its parts
     import importlib
+    import numpy as np
     synth = importlib.import_module("nimble-aligner_amd.synth")
     names, seqs = synth.make_library(40)
     obj = synth.library_json(names, seqs)
