@@ -1145,6 +1145,7 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   v.counted += B;
   for (int mt = 0; mt < 2; ++mt) {
     v.len[mt] += B;
+    v.alen[mt] += B;  // aliases len (a streamed call does not trim)
     v.pre[mt] += B;
     v.reason[mt] += B;
     v.score[mt] += B;
