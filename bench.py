@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
                     help="calls in flight at N=1: 2 = step i+1 runs on the GPU while the host finishes step i")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="rehearsal: run the multi-GPU step (route, all-to-all, reduce over RCCL) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
     args = ap.parse_args()
@@ -56,8 +58,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     L = 150
@@ -73,11 +79,14 @@ def main():
         torch.cuda.current_stream().synchronize()  # reads produced on torch's stream; the call runs on its own
         return lib.score_call(a, None, n=a.shape[0], fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
+    reducer = nd.TableReducer(device) if sharded else None
+
     def step():
         """One score::call: ends with the sorted rows materialised on the host (C++ result object)."""
-        if world > 1:
-            # pack locally -> exchange packed records by key hash (all-to-all) -> finish per rank -> all-reduce
-            return nd.sharded_call_packed(lib, reads, None, n, L, device)
+        if sharded:
+            # pack -> route by key hash (device kernels) -> all-to-all of the records -> unpack -> finish per rank
+            # -> all-reduce of the counts over the agreed callset table
+            return nd.sharded_step(lib, reads, None, n, L, device, reducer)
         return lib.score_call_raw(reads, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count
@@ -87,7 +96,7 @@ def main():
     counters = ctx.counters() if world == 1 else None
     ctx.set_counters(False)
 
-    depth = args.depth if world == 1 else 1
+    depth = args.depth if not sharded else 1
     ctxs = [lib.device_context(s) for s in range(depth)]
     for c in ctxs:
         c.set_counters(False)  # the work counters cost ~30 % of k_align; collected once, above
@@ -109,7 +118,7 @@ def main():
             begin(s)
         for s in range(depth):
             end(s)
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     stage = {k: 0.0 for k in stage}
@@ -160,7 +169,7 @@ def main():
             "reads_per_gpu": n, "read_len": L, "features": args.features,
             "parallelism": "1 process/GPU; reads hash-partitioned by key (all-to-all) + count all-reduce (RCCL)"
                            if world > 1 else "single GPU",
-            "rows": len(rows),
+            "rows": len(rows) if not sharded else len(reducer.rows(*rows)),
             "calls_in_flight": depth,
         },
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
@@ -231,9 +240,12 @@ def main():
                 "parity_on_sample": "bit-exact table (%d rows)" % len(got),
             }
             out["speedup_vs_cpu_baseline"] = value / (S / cpu_s)
+    if rank == 0 and getattr(nd, "_TIMING", None):
+        k = max(nd._TIMING.get("steps", 1), 1)
+        out["sharded_phase_ms"] = {a: round(b / k, 3) for a, b in nd._TIMING.items() if a != "steps"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -177,6 +177,15 @@ int nimble_pack(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, co
                 const nimble_packed *out);
 int nimble_call_packed(nimble_ctx *, const nimble_align_params *, const nimble_packed *in, uint64_t n,
                        uint32_t max_len);
+/* The exchange itself moves fixed-width records, one per read: key_words + 2 u64 = [key words ..., key hash,
+ * len0 | len1 << 16 | pre0 << 32 | pre1 << 40].  nimble_route_records groups the n packed reads by destination
+ * rank (key hash mod world; order inside a destination is arbitrary) into `records` (device, n * (key_words + 2)
+ * u64) and returns the number of records per destination in counts[world] (host) -- the split sizes of the
+ * all-to-all; complete on return.  nimble_unpack_records turns received records back into packed arrays on the
+ * context's stream (nimble_call_packed on the same context may follow without a wait). */
+int nimble_route_records(nimble_ctx *, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
+                         uint64_t *counts);
+int nimble_unpack_records(nimble_ctx *, const uint64_t *records, uint64_t n, const nimble_packed *out);
 
 /* ---- streamed form of the call: ONE score::call whose reads arrive in batches (a FASTQ file larger than one
  *      buffer; src/process/fastq.rs:15-29 feeds the whole file to a single score::call, so the dedup scope is

@@ -118,6 +118,10 @@ int nimble_score_call_packed(nimble_library *, const nimble_packed *in, uint64_t
 int nimble_score_call_fastq(nimble_library *, const char *r1_path, const char *r2_path, nimble_rows **out);
 void nimble_rows_free(nimble_rows *);
 uint64_t nimble_rows_count(const nimble_rows *);
+/* digest of the row keys in order, and the counts as an array: lets a multi-GPU driver re-use its key table from
+ * one call to the next and move only the counts */
+uint64_t nimble_rows_signature(const nimble_rows *);
+void nimble_rows_counts(const nimble_rows *, int64_t *out);
 /* features joined by '\t' (the TSV cell layout) and the count */
 const char *nimble_rows_get(const nimble_rows *, uint64_t i, int32_t *count);
 

@@ -133,6 +133,8 @@ def hip_lib():
         L.nimble_call_ex.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(CallExtra)]
         L.nimble_histogram_seg.argtypes = [vp, vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
         L.nimble_read_align_len.argtypes = [vp, i32, vp, u64]
+        L.nimble_route_records.argtypes = [vp, C.POINTER(NimblePacked), u64, u32, vp, vp]
+        L.nimble_unpack_records.argtypes = [vp, vp, u64, C.POINTER(NimblePacked)]
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
         _hip = L
@@ -386,7 +388,7 @@ HOST_SYMBOLS = [
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
-    "nimble_library_ctx_slot", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
+    "nimble_library_ctx_slot", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
 ]
 
@@ -441,6 +443,10 @@ def host_lib():
         L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
         L.nimble_library_ctx_slot.argtypes = [vp, i32]
         L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
+        L.nimble_rows_signature.argtypes = [vp]
+        L.nimble_rows_signature.restype = u64
+        L.nimble_rows_counts.argtypes = [vp, vp]
+        L.nimble_rows_counts.restype = None
         L.nimble_score_call_umis.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(UmiExtra), i32,
                                              C.POINTER(vp)]
         L.nimble_umi_rows_free.argtypes = [vp]
@@ -520,15 +526,22 @@ class PackedTensors:
 
     @classmethod
     def empty(cls, n, max_len, paired, device):
+        """Uninitialised arrays for nimble_pack / nimble_unpack_records to fill (they write every element; the
+        mate-1 arrays of a single-end set are zeroed).  Returns after torch's stream has finished with them, so a
+        kernel on the library's own stream may write them at once."""
         import torch
         kw = int(hip_lib().nimble_key_words(max_len, int(paired)))
         m = max(n, 1)
-        return cls(torch.zeros((kw, m), dtype=torch.int64, device=device)[:, :n],
-                   torch.zeros(m, dtype=torch.int32, device=device)[:n],
-                   torch.zeros(m, dtype=torch.int32, device=device)[:n],
-                   torch.zeros(m, dtype=torch.int64, device=device)[:n],
-                   torch.zeros(m, dtype=torch.uint8, device=device)[:n],
-                   torch.zeros(m, dtype=torch.uint8, device=device)[:n], max_len, paired)
+        mk = torch.empty if paired else torch.zeros
+        pt = cls(torch.empty((kw, m), dtype=torch.int64, device=device)[:, :n],
+                 torch.empty(m, dtype=torch.int32, device=device)[:n],
+                 mk(m, dtype=torch.int32, device=device)[:n],
+                 torch.empty(m, dtype=torch.int64, device=device)[:n],
+                 torch.empty(m, dtype=torch.uint8, device=device)[:n],
+                 mk(m, dtype=torch.uint8, device=device)[:n], max_len, paired)
+        if str(device).startswith("cuda"):
+            torch.cuda.current_stream(device).synchronize()
+        return pt
 
     def as_struct(self):
         st = NimblePacked()
@@ -549,6 +562,27 @@ class PackedTensors:
         meta = (self.len0.to(torch.int64) | (self.len1.to(torch.int64) << 16) | (self.pre0.to(torch.int64) << 32)
                 | (self.pre1.to(torch.int64) << 40))
         return torch.cat([self.keys.t(), self.hash[:, None], meta[:, None]], dim=1).contiguous()
+
+    def route(self, ctx, world):
+        """Group the reads by destination rank (key hash mod world) into exchange records with the device kernels
+        (nimble_route_records).  Returns (records [n, key_words + 2] int64 on the device, counts per rank list)."""
+        import torch
+        rec = torch.empty((max(self.n, 1), self.key_words + 2), dtype=torch.int64, device=self.keys.device)[:self.n]
+        counts = np.zeros(world, dtype=np.uint64)
+        st = self.as_struct()
+        _check(hip_lib().nimble_route_records(ctx.h, C.byref(st), self.n, world, rec.data_ptr(), counts.ctypes.data))
+        return rec, [int(c) for c in counts]
+
+    @classmethod
+    def unpack(cls, ctx, rec, key_words, max_len, paired):
+        """Received exchange records -> packed arrays (nimble_unpack_records, on the context's stream)."""
+        n = int(rec.shape[0])
+        pt = cls.empty(n, max_len, paired, rec.device)
+        assert pt.key_words == key_words
+        st = pt.as_struct()
+        pt._rec = rec  # keep the records alive until the kernel has run
+        _check(hip_lib().nimble_unpack_records(ctx.h, rec.data_ptr(), n, C.byref(st)))
+        return pt
 
     @classmethod
     def from_records(cls, rec, key_words, max_len, paired):
@@ -576,6 +610,21 @@ class RowsHandle:
             cnt = C.c_int32()
             out.append((L.nimble_rows_get(self.h, i, C.byref(cnt)).decode().split("\t"), cnt.value))
         return out
+
+    def signature(self):
+        """64-bit digest of the row keys (callsets, in order): equal digests = same keys in the same order."""
+        return int(host_lib().nimble_rows_signature(self.h))
+
+    def counts(self):
+        """int64 numpy array of the row counts, in row order."""
+        out = np.zeros(max(len(self), 1), dtype=np.int64)
+        host_lib().nimble_rows_counts(self.h, out.ctypes.data)
+        return out[:len(self)]
+
+    def keys(self):
+        L = host_lib()
+        cnt = C.c_int32()
+        return [L.nimble_rows_get(self.h, i, C.byref(cnt)).decode() for i in range(len(self))]
 
     def close(self):
         if getattr(self, "h", None):

@@ -122,6 +122,7 @@ struct nimble_ctx {
   uint32_t min_cov_len = 0;
   DevBuf b_out_c1, b_out_c2, b_out_cnt, b_out_seg, b_out_rep;
   // BAM-mode extras (nimble_call_ex)
+  DevBuf b_route;  // scratch of nimble_route_records
   DevBuf b_seg, b_alen[2], b_skip[2], b_qual[2], b_trim_ls, b_trim_qp, b_hist_rep;
   double trim_strictness = -1.0;
   uint64_t trim_target = ~0ULL;
@@ -154,7 +155,7 @@ struct nimble_ctx {
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
                       &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
                       &b_out_cnt, &b_out_seg, &b_out_rep, &b_seg, &b_alen[0], &b_alen[1], &b_skip[0], &b_skip[1], &b_qual[0],
-                      &b_qual[1], &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
+                      &b_qual[1], &b_route, &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
                       &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
       b->release();
     if (h2d_stream) {
@@ -963,6 +964,57 @@ int nimble_pack(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc) return rc;
   launch_pack(c->stream, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
               c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, c->cb);
+  HIPCHK(hipGetLastError());
+  return NIMBLE_OK;
+}
+
+// view of caller-owned packed arrays as CallBuffers (only the fields the exchange kernels touch)
+static void packed_view(CallBuffers &v, const nimble_packed *pk, uint64_t n) {
+  memset(&v, 0, sizeof v);
+  v.n = n;
+  v.key_stride = n;
+  v.key_words = pk->key_words;
+  v.paired = pk->paired ? 1 : 0;
+  v.keys = pk->keys;
+  v.key_hash = pk->hash;
+  for (int m = 0; m < 2; ++m) {
+    v.len[m] = pk->len[m];
+    v.pre[m] = pk->pre[m];
+  }
+}
+
+int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
+                         uint64_t *counts) {
+  if (!c || !in || !counts || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_route_records: NULL argument");
+  if (world == 0 || world > 256) return fail(NIMBLE_E_INVALID, "nimble_route_records: world must be 1..256");
+  if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0] || (in->paired && (!in->len[1] || !in->pre[1]))))
+    return fail(NIMBLE_E_INVALID, "nimble_route_records: packed arrays missing");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = c->b_state.ensure(16 * 8, &c->bytes);
+  if (rc) return rc;
+  const uint64_t cells = (uint64_t)route_grid() * world;
+  rc = c->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &c->bytes);
+  if (rc) return rc;
+  uint64_t *block_first = c->b_route.as<uint64_t>();
+  uint64_t *totals = block_first + cells;
+  uint32_t *block_counts = reinterpret_cast<uint32_t *>(totals + 256);
+  CallBuffers v;
+  packed_view(v, in, n);
+  launch_route(c->stream, v, world, block_counts, block_first, totals, records);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // counts are on the host and the records complete on return
+  return NIMBLE_OK;
+}
+
+int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, const nimble_packed *out) {
+  if (!c || !out || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_unpack_records: NULL argument");
+  if (n && (!out->keys || !out->hash || !out->len[0] || !out->pre[0] || (out->paired && (!out->len[1] || !out->pre[1]))))
+    return fail(NIMBLE_E_INVALID, "nimble_unpack_records: packed arrays missing");
+  HIPCHK(hipSetDevice(c->ix->device));
+  CallBuffers v;
+  packed_view(v, out, n);
+  launch_records_unpack(c->stream, records, v);
   HIPCHK(hipGetLastError());
   return NIMBLE_OK;
 }

@@ -98,6 +98,11 @@ void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uin
 void launch_maxinfo(hipStream_t s, const uint8_t *qual, const uint64_t *off, uint32_t fixed_len, uint64_t n,
                     const int64_t *length_scores, const int64_t *qual_probs, uint32_t *out);
 void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes);
+// multi-GPU exchange: route packed reads by key hash into fixed-width records, and back into the packed arrays
+uint32_t route_grid();  // blocks of the routing kernels (sizes block_counts / block_first: grid * world entries)
+void launch_route(hipStream_t s, const CallBuffers &cb, uint32_t world, uint32_t *block_counts, uint64_t *block_first,
+                  uint64_t *totals, uint64_t *rec);
+void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb);
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
 
 uint32_t align_ws_lanes();   // lanes of the align grid (sizes ws_cols)

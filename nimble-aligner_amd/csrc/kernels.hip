@@ -237,6 +237,8 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     h = (h ^ word) * 0xff51afd7ed558ccdULL;
     h ^= h >> 32;
   }
+  // words past the end of the key stay defined (the exchange copies whole records)
+  for (uint32_t z = w + (nb ? 1u : 0u); z < cb.key_words; ++z) cb.keys[(uint64_t)z * cb.key_stride + r] = 0ULL;
   cb.key_hash[r] = mix64(h);
 }
 
@@ -1167,6 +1169,124 @@ __global__ void k_hist_dense_se(CallBuffers cb, int64_t *counts, uint32_t n_clas
   if (c2 == CLS_NONE && c1 < n_classes) counts[c1] = (int64_t)cb.hist_cnt[i];
 }
 
+// ---- exchange helpers (multi-GPU): reads routed by key hash as fixed-width records ---------------------
+// record = [key words ..., key hash, len0 | len1 << 16 | pre0 << 32 | pre1 << 40]  (key_words + 2 u64)
+__device__ __forceinline__ uint32_t route_of(uint64_t h, uint32_t world) {
+  return (uint32_t)((h & 0x7FFFFFFFFFFFFFFFULL) % world);
+}
+
+// Two passes over a fixed block -> reads mapping (block b owns the tiles b, b + G, b + 2G, ... of 256 reads), no
+// global atomics: pass 1 leaves per-block counts, a one-block scan turns them into the first record slot of every
+// (block, destination), pass 2 hands out slots from LDS cursors.  The layout is deterministic.
+constexpr uint32_t ROUTE_GRID = 2048;
+
+__global__ void k_route_count(const uint64_t *__restrict__ hash, uint64_t n, uint32_t world, uint32_t *block_counts) {
+  __shared__ uint32_t s_c[256];
+  if (threadIdx.x < world) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint64_t tile = blockIdx.x; tile * 256 < n; tile += gridDim.x) {
+    const uint64_t i = tile * 256 + threadIdx.x;
+    const uint32_t d = i < n ? route_of(hash[i], world) : 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < world; ++t) {
+      const uint64_t m = __ballot(d == t);
+      if (lane == 0 && m) atomicAdd(&s_c[t], (uint32_t)__popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < world) block_counts[(uint64_t)blockIdx.x * world + threadIdx.x] = s_c[threadIdx.x];
+}
+
+// one block of 256 threads: totals[t] and block_first[b][t] = first record slot of (block b, destination t).
+// Thread j owns the n_blocks / 256 consecutive blocks starting at j * per; a block-wide scan joins the chunks.
+__global__ void k_route_scan(const uint32_t *__restrict__ block_counts, uint32_t n_blocks, uint32_t world,
+                             uint64_t *totals, uint64_t *block_first) {
+  __shared__ uint64_t s_part[256];
+  __shared__ uint64_t s_start;
+  const uint32_t j = threadIdx.x;
+  const uint32_t per = (n_blocks + 255u) / 256u;
+  if (j == 0) s_start = 0;
+  __syncthreads();
+  for (uint32_t t = 0; t < world; ++t) {
+    uint64_t mine = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t b = j * per + k;
+      if (b < n_blocks) mine += block_counts[(uint64_t)b * world + t];
+    }
+    s_part[j] = mine;
+    __syncthreads();
+    // inclusive scan over the 256 partial sums (Hillis-Steele; 8 steps)
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      const uint64_t v = j >= d ? s_part[j - d] : 0;
+      __syncthreads();
+      s_part[j] += v;
+      __syncthreads();
+    }
+    uint64_t run = s_start + s_part[j] - mine;  // first slot of this thread's chunk
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t b = j * per + k;
+      if (b < n_blocks) {
+        block_first[(uint64_t)b * world + t] = run;
+        run += block_counts[(uint64_t)b * world + t];
+      }
+    }
+    __syncthreads();
+    if (j == 255) {
+      totals[t] = s_part[255];
+      s_start += s_part[255];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_route_scatter(CallBuffers cb, uint32_t world, const uint64_t *__restrict__ block_first,
+                                uint64_t *__restrict__ rec) {
+  __shared__ unsigned long long s_cur[256];
+  if (threadIdx.x < world) s_cur[threadIdx.x] = block_first[(uint64_t)blockIdx.x * world + threadIdx.x];
+  __syncthreads();
+  const uint32_t kw = cb.key_words;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint64_t tile = blockIdx.x; tile * 256 < cb.n; tile += gridDim.x) {
+    const uint64_t i = tile * 256 + threadIdx.x;
+    const bool live = i < cb.n;
+    const uint64_t h = live ? cb.key_hash[i] : 0;
+    const uint32_t d = live ? route_of(h, world) : 0xFFFFFFFFu;
+    uint64_t slot = 0;
+    for (uint32_t t = 0; t < world; ++t) {
+      const uint64_t m = __ballot(d == t);
+      if (m == 0) continue;
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&s_cur[t], (unsigned long long)__popcll(m));
+      base = __shfl(base, (int)leader, 64);
+      if (d == t) slot = base + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    }
+    if (live) {
+      uint64_t *o = rec + slot * (kw + 2);
+      for (uint32_t w = 0; w < kw; ++w) o[w] = cb.keys[(uint64_t)w * cb.key_stride + i];
+      o[kw] = h;
+      o[kw + 1] = (uint64_t)cb.len[0][i] | ((uint64_t)(cb.paired ? cb.len[1][i] : 0u) << 16) |
+                  ((uint64_t)cb.pre[0][i] << 32) | ((uint64_t)(cb.paired ? cb.pre[1][i] : 0u) << 40);
+    }
+  }
+}
+
+__global__ void k_records_unpack(const uint64_t *__restrict__ rec, CallBuffers cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cb.n) return;
+  const uint32_t kw = cb.key_words;
+  const uint64_t *o = rec + i * (kw + 2);
+  for (uint32_t w = 0; w < kw; ++w) cb.keys[(uint64_t)w * cb.key_stride + i] = o[w];
+  cb.key_hash[i] = o[kw];
+  const uint64_t meta = o[kw + 1];
+  cb.len[0][i] = (uint32_t)(meta & 0xFFFF);
+  cb.pre[0][i] = (uint8_t)((meta >> 32) & 0xFF);
+  if (cb.paired) {
+    cb.len[1][i] = (uint32_t)((meta >> 16) & 0xFFFF);
+    cb.pre[1][i] = (uint8_t)((meta >> 40) & 0xFF);
+  }
+}
+
 __global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1256,6 +1376,17 @@ void launch_maxinfo(hipStream_t s, const uint8_t *qual, const uint64_t *off, uin
 void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts, uint32_t n_classes) {
   hipLaunchKernelGGL(k_hist_dense_se, dim3(blocks_for(cb.hist_mask + 1, 256)), dim3(256), 0, s, cb, counts,
                      n_classes);
+}
+uint32_t route_grid() { return ROUTE_GRID; }
+void launch_route(hipStream_t s, const CallBuffers &cb, uint32_t world, uint32_t *block_counts, uint64_t *block_first,
+                  uint64_t *totals, uint64_t *rec) {
+  hipLaunchKernelGGL(k_route_count, dim3(ROUTE_GRID), dim3(256), 0, s, cb.key_hash, cb.n, world, block_counts);
+  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(256), 0, s, block_counts, ROUTE_GRID, world, totals, block_first);
+  if (cb.n) hipLaunchKernelGGL(k_route_scatter, dim3(ROUTE_GRID), dim3(256), 0, s, cb, world, block_first, rec);
+}
+void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_records_unpack, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, rec, cb);
 }
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n) {
   if (n == 0) return;

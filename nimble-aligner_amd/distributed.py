@@ -16,8 +16,14 @@ has one real exchange step and one reduction:
 The replicated index makes class contents identical on every rank; callsets (lists of feature names)
 are therefore global keys, and their union is agreed on with one all_gather_object of the key lists.
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
+
+# NIMBLE_DIST_TIMING=1: accumulate wall milliseconds per phase of sharded_step (adds synchronisation; diagnostics)
+_TIMING = {} if os.environ.get("NIMBLE_DIST_TIMING") else None
 
 
 def _weights(width, device):
@@ -104,6 +110,98 @@ def reduce_tables(rows, device, group=None):
     dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     counts = vec.tolist()
     return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
+
+
+def exchange_routed(rec, counts, group=None):
+    """all_to_all of records already grouped by destination rank (`counts` records per rank)."""
+    world = dist.get_world_size(group)
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=rec.device)
+    recv = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv, send_counts, group=group)
+    out_split = recv.tolist()
+    got = torch.empty((sum(out_split), rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_to_all_single(got, rec, output_split_sizes=out_split, input_split_sizes=list(counts), group=group)
+    return got
+
+
+class TableReducer:
+    """Per-callset counts summed over ranks, call after call.  The union of the callsets is agreed on once (one
+    all_gather_object) and kept; as long as no rank's key list changes, a call moves only a dense int64 vector
+    (one all_reduce; its last element flags a change, which triggers a new agreement)."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = device, group
+        self.sig = None          # digest of this rank's key list at the last agreement
+        self.universe = []       # sorted union of the keys of all ranks
+        self.local2uni = None    # position of each local row in the universe
+
+    def _agree(self, keys):
+        world = dist.get_world_size(self.group)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, keys, group=self.group)
+        self.universe = sorted(set(k for ks in gathered for k in ks), key=lambda s: s.split("\t"))
+        pos = {k: i for i, k in enumerate(self.universe)}
+        self.local2uni = torch.tensor([pos[k] for k in keys], dtype=torch.int64, device=self.device)
+
+    def reduce(self, keys_fn, counts, sig):
+        """keys_fn() -> list of '\t'-joined callsets (only called when an agreement is needed); counts: int64
+        numpy array in the same order; sig: digest of the key list.  Returns (universe keys, summed counts tensor)."""
+        changed = sig != self.sig
+        for attempt in range(2):
+            vec = torch.zeros(len(self.universe) + 1, dtype=torch.int64, device=self.device)
+            if not changed and counts.size:
+                vec.index_add_(0, self.local2uni, torch.from_numpy(counts).to(self.device))
+            vec[-1] = 1 if changed else 0
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+            if int(vec[-1].item()) == 0:
+                return self.universe, vec[:-1]
+            # some rank has new keys: every rank re-agrees, then the counts go round again
+            self._agree(keys_fn())
+            self.sig = sig
+            changed = False
+        raise RuntimeError("TableReducer: key agreement did not settle")
+
+    def rows(self, universe, vec):
+        counts = vec.tolist()
+        return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
+
+
+def sharded_step(lib, r1, r2, n, fixed_len, device, reducer, group=None):
+    """One multi-GPU step with device-side routing and the cached key table: pack -> route (device kernels) ->
+    all_to_all of the records -> unpack -> rest of score::call -> all_reduce of the counts.  Returns
+    (universe keys, summed counts tensor); reducer.rows() turns them into the merged table."""
+    nim = __import__("importlib").import_module("nimble-aligner_amd")
+    world = dist.get_world_size(group)
+    ctx = lib.device_context()
+    timing = _TIMING is not None
+    t = [time.perf_counter()] if timing else None
+
+    def mark():
+        if timing:
+            torch.cuda.synchronize()
+            ctx.synchronize()
+            t.append(time.perf_counter())
+
+    pt = lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=nim.MEM_DEVICE,
+                  device=str(device))
+    mark()
+    rec, counts = pt.route(ctx, world)                  # complete on return
+    mark()
+    got = exchange_routed(rec, counts, group)
+    torch.cuda.current_stream().synchronize()           # the records arrive on torch's stream
+    mark()
+    shard = nim.PackedTensors.unpack(ctx, got, pt.key_words, pt.max_len, pt.paired)
+    mark()
+    rows = lib.score_call_packed(shard, raw=True)
+    mark()
+    out = reducer.reduce(rows.keys, rows.counts(), rows.signature())
+    mark()
+    if timing:
+        names = ("pack", "route", "exchange", "unpack", "call", "reduce")
+        for k, (a, b) in zip(names, zip(t[:-1], t[1:])):
+            _TIMING[k] = _TIMING.get(k, 0.0) + (b - a) * 1e3
+        _TIMING["steps"] = _TIMING.get("steps", 0) + 1
+    return out
 
 
 def sharded_call_packed(lib, r1, r2, n, fixed_len, device, group=None, raw=False):

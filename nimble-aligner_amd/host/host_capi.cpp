@@ -348,6 +348,17 @@ int nimble_score_call_fastq(nimble_library *l, const char *p1, const char *p2, n
 }
 
 void nimble_rows_free(nimble_rows *r) { delete r; }
+uint64_t nimble_rows_signature(const nimble_rows *r) {
+  uint64_t h = 1469598103934665603ULL ^ (uint64_t)r->joined.size();
+  for (const std::string &s : r->joined) {
+    for (unsigned char ch : s) h = (h ^ ch) * 1099511628211ULL;
+    h = (h ^ 0xFFu) * 1099511628211ULL;
+  }
+  return h;
+}
+void nimble_rows_counts(const nimble_rows *r, int64_t *out) {
+  for (size_t i = 0; i < r->rows.size(); ++i) out[i] = r->rows[i].second;
+}
 uint64_t nimble_rows_count(const nimble_rows *r) { return r->rows.size(); }
 const char *nimble_rows_get(const nimble_rows *r, uint64_t i, int32_t *count) {
   *count = r->rows.at(i).second;

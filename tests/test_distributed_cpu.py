@@ -148,3 +148,51 @@ def test_exchange_records_routes_every_record_to_its_hash_rank(tmp_path):
         key = lambda t: sorted(map(tuple, t.tolist()))
         assert key(got[r]) == key(want)
     assert sum(g.shape[0] for g in got) == allsent.shape[0]
+
+
+def _reducer_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nd = importlib.import_module("nimble-aligner_amd.distributed")
+    red = nd.TableReducer(torch.device("cpu"))
+    calls = {"keys": 0}
+
+    def run(keys, counts):
+        def keys_fn():
+            calls["keys"] += 1
+            return keys
+        uni, vec = red.reduce(keys_fn, np.asarray(counts, dtype=np.int64), hash(tuple(keys)))
+        return red.rows(uni, vec)
+
+    out = []
+    # call 1: disjoint + shared keys; call 2: same keys, other counts (no new agreement); call 3: rank 1 gets a new key
+    k = [["a\tb", "c"], ["c", "d"]][rank]
+    out.append(run(k, [1 + rank, 10]))
+    out.append(run(k, [5, 7 + rank]))
+    agreed = calls["keys"]
+    k2 = k + (["e"] if rank == 1 else [])
+    out.append(run(k2, [1, 1] + ([4] if rank == 1 else [])))
+    out.append(run(k2, [0, 2] + ([0] if rank == 1 else [])))
+    q.put((rank, out, agreed, calls["keys"]))
+    dist.destroy_process_group()
+
+
+def test_table_reducer_caches_the_key_agreement():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, agreed, total in res:
+        assert out[0] == [(["a", "b"], 1), (["c"], 12), (["d"], 10)]
+        assert out[1] == [(["a", "b"], 5), (["c"], 12), (["d"], 8)]
+        assert out[2] == [(["a", "b"], 1), (["c"], 2), (["d"], 1), (["e"], 4)]
+        assert out[3] == [(["c"], 2), (["d"], 2)]
+        assert agreed == 1 and total == 2      # keys were exchanged once per change, not once per call

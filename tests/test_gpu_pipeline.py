@@ -379,3 +379,46 @@ def test_fastq_pipeline_streams_batches(synth_lib, tmp_path, monkeypatch):
     out = str(tmp_path / "mixed.tsv")
     nim.fastq_process([mixed], [lib], [out])
     assert open(out).read() == "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_device_routing_of_exchange_records(synth_lib, paired):
+    # nimble_route_records / nimble_unpack_records: every read lands in the bucket of hash % world, buckets are
+    # contiguous with the reported sizes, and finishing each bucket separately adds up to the direct call
+    torch = pytest.importorskip("torch")
+    nd = importlib.import_module("nimble-aligner_amd.distributed")
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    ctx = lib.device_context()
+    n = 50_001
+    if paired:
+        r1, r2 = synth.make_reads(seqs, n, paired=True, seed=611)
+    else:
+        r1, r2 = synth.make_reads(seqs, n, seed=610), None
+    o = synth.fixed_offsets(n, 150)
+    direct = lib.score_call(r1.reshape(-1), o, None if r2 is None else r2.reshape(-1), None if r2 is None else o)
+    d1 = torch.from_numpy(r1.copy()).to("cuda:0")
+    d2 = None if r2 is None else torch.from_numpy(r2.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    pt = lib.pack(d1, None, d2, None, n=n, fixed_len=150, max_len=150, mem=nim.MEM_DEVICE)
+    ctx.synchronize()
+    ref_rec = pt.to_records()
+    for world in (1, 3, 8):
+        rec, counts = pt.route(ctx, world)
+        assert sum(counts) == n and len(counts) == world
+        dest = nd.hash_partition(pt.hash, world)
+        assert counts == torch.bincount(dest, minlength=world).tolist()
+        # same multiset of records per bucket as the torch formulation
+        lo = 0
+        merged = {}
+        for rank in range(world):
+            part = rec[lo:lo + counts[rank]]
+            lo += counts[rank]
+            want = ref_rec[dest == rank]
+            a = part[torch.argsort(part[:, pt.key_words], stable=True)]
+            b = want[torch.argsort(want[:, pt.key_words], stable=True)]
+            assert torch.equal(torch.sort(a.reshape(-1))[0], torch.sort(b.reshape(-1))[0])
+            shard = nim.PackedTensors.unpack(ctx, part.contiguous(), pt.key_words, pt.max_len, pt.paired)
+            for f, c in lib.score_call_packed(shard):
+                merged[tuple(f)] = merged.get(tuple(f), 0) + c
+        assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
