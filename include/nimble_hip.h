@@ -101,7 +101,13 @@ void *nimble_ctx_stream(nimble_ctx *);
 
 /* Options: NIMBLE_OPT_COUNTERS (default 1) -- collect the work counters of nimble_call_counters inside the
  * align kernel; switch off for timed runs. */
-enum { NIMBLE_OPT_COUNTERS = 1 };
+enum {
+  NIMBLE_OPT_COUNTERS = 1,
+  /* percent (10..100, default 100) of the resident block slots the persistent align grid takes.  Below 100 every
+   * CU keeps room for the kernels of another stream -- a multi-GPU pipeline sets 87 so that RCCL's exchange of the
+   * next batch runs beside the align kernel instead of behind it */
+  NIMBLE_OPT_ALIGN_GRID_PCT = 2
+};
 int nimble_ctx_set_option(nimble_ctx *, int option, int64_t value);
 
 /* Memory space of the read buffers handed to nimble_call */

@@ -62,7 +62,7 @@ int nimble_library_build_index(nimble_library *, int device);
 /* the device handles behind the library's PseudoAligner (NULL before build_index); borrowed */
 void *nimble_library_index(nimble_library *);
 void *nimble_library_ctx(nimble_library *);
-void *nimble_library_ctx_slot(nimble_library *, int slot); /* context of a begin/end slot (0 or 1); NULL on error */
+void *nimble_library_ctx_slot(nimble_library *, int slot); /* context of slot 0 / 1 (calls) or 2 (utility); NULL on error */
 
 /* score::call.  r2 == NULL for single-end; *_off == NULL means fixed_len; mem as in nimble_hip.h */
 int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
@@ -114,6 +114,13 @@ int nimble_library_pack(nimble_library *, const uint8_t *r1, const uint64_t *r1_
                         const nimble_packed *out);
 int nimble_score_call_packed(nimble_library *, const nimble_packed *in, uint64_t n, uint32_t max_len,
                              nimble_rows **out);
+/* the same, for a pipeline that keeps calls in flight while the next batch is packed and exchanged: pack on a
+ * given context slot (2 = the utility context, free of calls), begin the packed call on slot 0 / 1 and collect it
+ * with nimble_score_call_end */
+int nimble_library_pack_slot(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                             const nimble_packed *out);
+int nimble_score_call_packed_begin(nimble_library *, int slot, const nimble_packed *in, uint64_t n, uint32_t max_len);
 /* get_error_checked_fastq_readers + score::call */
 int nimble_score_call_fastq(nimble_library *, const char *r1_path, const char *r2_path, nimble_rows **out);
 void nimble_rows_free(nimble_rows *);

@@ -23,6 +23,7 @@ HIP_LIB_PATH = os.environ.get("NIMBLE_HIP_LIB") or os.path.join(LIB_DIR, "libnim
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_host.so")
 
 CLASS_NONE = 0xFFFFFFFF
+OPT_COUNTERS, OPT_ALIGN_GRID_PCT = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
 REASONS = {
@@ -331,6 +332,9 @@ class Context:
     def synchronize(self):
         _check(hip_lib().nimble_ctx_synchronize(self.h))
 
+    def set_option(self, option, value):
+        _check(hip_lib().nimble_ctx_set_option(self.h, option, int(value)))
+
     def set_counters(self, on):
         _check(hip_lib().nimble_ctx_set_option(self.h, 1, int(bool(on))))
 
@@ -388,7 +392,7 @@ HOST_SYMBOLS = [
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
-    "nimble_library_ctx_slot", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
+    "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
 ]
 
@@ -443,6 +447,8 @@ def host_lib():
         L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
         L.nimble_library_ctx_slot.argtypes = [vp, i32]
         L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
+        L.nimble_library_pack_slot.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
+        L.nimble_score_call_packed_begin.argtypes = [vp, i32, C.POINTER(NimblePacked), u64, u32]
         L.nimble_rows_signature.argtypes = [vp]
         L.nimble_rows_signature.restype = u64
         L.nimble_rows_counts.argtypes = [vp, vp]
@@ -563,21 +569,24 @@ class PackedTensors:
                 | (self.pre1.to(torch.int64) << 40))
         return torch.cat([self.keys.t(), self.hash[:, None], meta[:, None]], dim=1).contiguous()
 
-    def route(self, ctx, world):
+    def route(self, ctx, world, out=None):
         """Group the reads by destination rank (key hash mod world) into exchange records with the device kernels
-        (nimble_route_records).  Returns (records [n, key_words + 2] int64 on the device, counts per rank list)."""
+        (nimble_route_records).  Returns (records [n, key_words + 2] int64 on the device, counts per rank list).
+        out: a records tensor of that shape to fill (re-used buffers keep the allocator out of the pipeline)."""
         import torch
-        rec = torch.empty((max(self.n, 1), self.key_words + 2), dtype=torch.int64, device=self.keys.device)[:self.n]
+        rec = out if out is not None else torch.empty((max(self.n, 1), self.key_words + 2), dtype=torch.int64,
+                                                      device=self.keys.device)[:self.n]
+        assert tuple(rec.shape) == (self.n, self.key_words + 2) and rec.is_contiguous()
         counts = np.zeros(world, dtype=np.uint64)
         st = self.as_struct()
         _check(hip_lib().nimble_route_records(ctx.h, C.byref(st), self.n, world, rec.data_ptr(), counts.ctypes.data))
         return rec, [int(c) for c in counts]
 
     @classmethod
-    def unpack(cls, ctx, rec, key_words, max_len, paired):
+    def unpack(cls, ctx, rec, key_words, max_len, paired, out=None):
         """Received exchange records -> packed arrays (nimble_unpack_records, on the context's stream)."""
         n = int(rec.shape[0])
-        pt = cls.empty(n, max_len, paired, rec.device)
+        pt = out if out is not None and out.n == n else cls.empty(n, max_len, paired, rec.device)
         assert pt.key_words == key_words
         st = pt.as_struct()
         pt._rec = rec  # keep the records alive until the kernel has run
@@ -804,17 +813,24 @@ class Library:
         return self.score_call(b1, o1)
 
     def pack(self, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST,
-             device="cuda:0"):
+             device="cuda:0", slot=0, out=None):
         """First half of the split call: 2-bit packed keys, lengths, key hash and prefilter verdicts written into
-        torch tensors on `device` (a PackedTensors), ready to be exchanged between ranks."""
+        torch tensors on `device` (a PackedTensors), ready to be exchanged between ranks.  slot: the context that
+        runs the kernel (2 = the utility context, for use while calls are in flight on slots 0 / 1)."""
         if r1_off is not None and n is None:
             n = int(len(r1_off) - 1)
         max_len = max(max_len or fixed_len, 1)
-        pt = PackedTensors.empty(n, max_len, r2 is not None, device)
+        pt = out if out is not None and out.n == n else PackedTensors.empty(n, max_len, r2 is not None, device)
         st = pt.as_struct()
-        _hcheck(host_lib().nimble_library_pack(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
-                                               max_len, mem, C.byref(st)))
+        _hcheck(host_lib().nimble_library_pack_slot(self.h, slot, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+                                                    fixed_len, max_len, mem, C.byref(st)))
         return pt
+
+    def score_call_packed_begin(self, slot, pt):
+        """Enqueue the second half of the split call on slot 0 / 1; collect it with score_call_end(slot).  `pt` must
+        stay alive until then."""
+        st = pt.as_struct()
+        _hcheck(host_lib().nimble_score_call_packed_begin(self.h, slot, C.byref(st), pt.n, pt.max_len))
 
     def score_call_packed(self, pt, raw=False):
         """Second half of the split call: score::call from packed arrays (possibly received from other ranks)."""

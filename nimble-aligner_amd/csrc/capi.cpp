@@ -80,12 +80,17 @@ struct DevBuf {
 
 struct nimble_index {
   int device = 0;
+  // One result stream for all contexts of the index.  HIP multiplexes streams onto a few hardware queues
+  // (GPU_MAX_HW_QUEUES, 4 by default); two streams that share a queue run in order, so every extra stream makes it
+  // likelier that somebody else's stream (RCCL's) lands behind the launch stream's persistent kernels.
+  hipStream_t copy_stream = nullptr;
   DevIndex dev{};
   DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     for (DevBuf *b : {&b_ht, &b_bitmap, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_intern,
                       &b_dyn_state})
       b->release();
@@ -133,6 +138,7 @@ struct nimble_ctx {
   bool have_events = false;
   bool called = false;
   int want_counters = 1;
+  int align_grid_pct = 100;
   uint32_t dyn_before = 0, dyn_after = 0;
   // arguments of the call in flight (kept so that finish_call can re-enqueue after growing a pool)
   nimble_align_params prm{};
@@ -168,7 +174,6 @@ struct nimble_ctx {
     if (have_events)
       for (auto &e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (p_state) (void)hipHostFree(p_state);
     if (p_dyn) (void)hipHostFree(p_dyn);
   }
@@ -341,7 +346,7 @@ int enqueue_call(nimble_ctx *c) {
     launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
                 c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
   HIPCHK(hipEventRecord(c->ev[1], s));
-  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters);
+  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct);
   return enqueue_tail(c);
 }
 
@@ -653,7 +658,10 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
     }
   }
   c->have_events = true;
-  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (!ix->copy_stream && hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking) != hipSuccess)
+    ix->copy_stream = nullptr;
+  c->copy_stream = ix->copy_stream;
+  if (!c->copy_stream ||
       hipHostMalloc((void **)&c->p_state, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void **)&c->p_dyn, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
     delete c;
@@ -677,6 +685,11 @@ int nimble_ctx_set_option(nimble_ctx *c, int option, int64_t value) {
   if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
   if (option == NIMBLE_OPT_COUNTERS) {
     c->want_counters = value != 0;
+    return NIMBLE_OK;
+  }
+  if (option == NIMBLE_OPT_ALIGN_GRID_PCT) {
+    if (value < 10 || value > 100) return fail(NIMBLE_E_INVALID, "NIMBLE_OPT_ALIGN_GRID_PCT: 10..100");
+    c->align_grid_pct = (int)value;
     return NIMBLE_OK;
   }
   return fail(NIMBLE_E_INVALID, "nimble_ctx_set_option: unknown option");
@@ -1216,7 +1229,7 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
     c->stage_busy[k] = true;
     c->stage_k ^= 1;
   }
-  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters);
+  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
   HIPCHK(hipGetLastError());
   if (mem == NIMBLE_MEM_HOST) HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
   c->stream_n += m;

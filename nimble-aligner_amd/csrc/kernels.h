@@ -86,7 +86,7 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
                  uint32_t fixed_len, uint32_t max_len, uint32_t min_len, const double *plog, uint32_t plog_max_len,
                  const CallBuffers &cb);
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters);
+                  int want_counters, int grid_pct = 100);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb);

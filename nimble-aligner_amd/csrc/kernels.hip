@@ -1317,7 +1317,7 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
 }
 
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters) {
+                  int want_counters, int grid_pct) {
   if (cb.n == 0) return;
   uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
   size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
@@ -1336,7 +1336,11 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
     int g = per_cu * cus;
     resident_cache[key] = g > ALIGN_GRID ? ALIGN_GRID : g;
   }
-  uint32_t grid = (uint32_t)(tiles < (uint64_t)resident_cache[key] ? tiles : (uint64_t)resident_cache[key]);
+  // grid_pct < 100 leaves block slots free on every CU: a persistent grid that fills the chip would keep the
+  // kernels of another stream (RCCL's exchange) waiting until it ends
+  uint64_t resident = (uint64_t)resident_cache[key] * (uint64_t)(grid_pct < 10 ? 10 : (grid_pct > 100 ? 100 : grid_pct)) / 100;
+  if (resident < 1) resident = 1;
+  uint32_t grid = (uint32_t)(tiles < resident ? tiles : resident);
   if (cb.paired) {
     if (want_counters) hipLaunchKernelGGL((k_align<true, true>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
     else hipLaunchKernelGGL((k_align<true, false>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);

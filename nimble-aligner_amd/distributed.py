@@ -26,6 +26,44 @@ import torch.distributed as dist
 _TIMING = {} if os.environ.get("NIMBLE_DIST_TIMING") else None
 
 
+class _Staging:
+    """Small host <-> device transfers through page-locked buffers on the current stream.  Pageable copies
+    (torch.tensor(list, device=...), .tolist(), .item()) were measured to wait for whatever runs on the library's
+    launch stream -- 2.5 ms behind a call in flight -- page-locked non_blocking copies do not."""
+
+    def __init__(self, device):
+        self.device = device
+        self.pins = {}
+
+    def _pin(self, tag, n):
+        t = self.pins.get(tag)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 16), dtype=torch.int64)
+            if torch.device(self.device).type == "cuda":
+                t = t.pin_memory()
+            self.pins[tag] = t
+        return t[:n]
+
+    def to_device(self, tag, values, out=None):
+        """values: sequence / int64 numpy array -> int64 device tensor."""
+        n = len(values)
+        pin = self._pin(("h2d", tag), n)
+        if n:
+            pin.copy_(torch.as_tensor(values, dtype=torch.int64))
+        dst = out if out is not None else torch.empty(n, dtype=torch.int64, device=self.device)
+        dst.copy_(pin, non_blocking=True)
+        return dst
+
+    def to_host(self, tag, tensor):
+        """int64 device tensor -> list, after a synchronisation of the current stream only."""
+        n = tensor.numel()
+        pin = self._pin(("d2h", tag), n)
+        pin.copy_(tensor.reshape(-1), non_blocking=True)
+        if tensor.is_cuda:
+            torch.cuda.current_stream(tensor.device).synchronize()
+        return pin.tolist()
+
+
 def _weights(width, device):
     g = torch.Generator(device="cpu")
     g.manual_seed(0x6E696D62)
@@ -112,14 +150,16 @@ def reduce_tables(rows, device, group=None):
     return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
 
 
-def exchange_routed(rec, counts, group=None):
-    """all_to_all of records already grouped by destination rank (`counts` records per rank)."""
-    world = dist.get_world_size(group)
-    send_counts = torch.tensor(counts, dtype=torch.int64, device=rec.device)
+def exchange_routed(rec, counts, group=None, alloc=None, staging=None):
+    """all_to_all of records already grouped by destination rank (`counts` records per rank).  alloc(rows) may
+    supply the receive buffer; staging (a _Staging) keeps the small host <-> device copies page-locked."""
+    st = staging or _Staging(rec.device)
+    send_counts = st.to_device("send_counts", counts)
     recv = torch.empty_like(send_counts)
     dist.all_to_all_single(recv, send_counts, group=group)
-    out_split = recv.tolist()
-    got = torch.empty((sum(out_split), rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    out_split = st.to_host("recv_counts", recv)
+    rows = sum(out_split)
+    got = alloc(rows) if alloc else torch.empty((rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_to_all_single(got, rec, output_split_sizes=out_split, input_split_sizes=list(counts), group=group)
     return got
 
@@ -134,6 +174,7 @@ class TableReducer:
         self.sig = None          # digest of this rank's key list at the last agreement
         self.universe = []       # sorted union of the keys of all ranks
         self.local2uni = None    # position of each local row in the universe
+        self.staging = _Staging(device)
 
     def _agree(self, keys):
         world = dist.get_world_size(self.group)
@@ -141,7 +182,7 @@ class TableReducer:
         dist.all_gather_object(gathered, keys, group=self.group)
         self.universe = sorted(set(k for ks in gathered for k in ks), key=lambda s: s.split("\t"))
         pos = {k: i for i, k in enumerate(self.universe)}
-        self.local2uni = torch.tensor([pos[k] for k in keys], dtype=torch.int64, device=self.device)
+        self.local2uni = self.staging.to_device("local2uni", [pos[k] for k in keys]).clone()
 
     def reduce(self, keys_fn, counts, sig):
         """keys_fn() -> list of '\t'-joined callsets (only called when an agreement is needed); counts: int64
@@ -150,19 +191,21 @@ class TableReducer:
         for attempt in range(2):
             vec = torch.zeros(len(self.universe) + 1, dtype=torch.int64, device=self.device)
             if not changed and counts.size:
-                vec.index_add_(0, self.local2uni, torch.from_numpy(counts).to(self.device))
-            vec[-1] = 1 if changed else 0
+                vec.index_add_(0, self.local2uni, self.staging.to_device("counts", counts))
+            if changed:
+                vec[-1:] += 1
             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
-            if int(vec[-1].item()) == 0:
-                return self.universe, vec[:-1]
+            host = self.staging.to_host("vec", vec)
+            if host[-1] == 0:
+                return self.universe, host[:-1]
             # some rank has new keys: every rank re-agrees, then the counts go round again
             self._agree(keys_fn())
             self.sig = sig
             changed = False
         raise RuntimeError("TableReducer: key agreement did not settle")
 
-    def rows(self, universe, vec):
-        counts = vec.tolist()
+    def rows(self, universe, counts):
+        counts = counts.tolist() if hasattr(counts, "tolist") else counts
         return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
 
 
@@ -202,6 +245,112 @@ def sharded_step(lib, r1, r2, n, fixed_len, device, reducer, group=None):
             _TIMING[k] = _TIMING.get(k, 0.0) + (b - a) * 1e3
         _TIMING["steps"] = _TIMING.get("steps", 0) + 1
     return out
+
+
+class ShardedPipeline:
+    """The multi-GPU step, software-pipelined over successive batches.  For batch b:
+         P(b) pack + route            launch stream (utility context)
+         X(b) all_to_all of records   RCCL, overlaps C(b-1) on the device
+         C(b) unpack + packed call    launch stream, call slot b % 2
+         F(b) rows + count all-reduce host + one small RCCL all_reduce
+    submit(b) runs P(b), enqueues C(b-1), runs X(b) and returns F(b-2): the launch stream always holds the next
+    kernels, the exchange and the host work hide behind a call.  flush() drains the last two batches."""
+
+    def __init__(self, lib, device, reducer, group=None, align_grid_pct=87):
+        self.nim = __import__("importlib").import_module("nimble-aligner_amd")
+        self.lib, self.device, self.reducer, self.group = lib, device, reducer, group
+        self.world = dist.get_world_size(group)
+        self.util = lib.device_context(2)
+        # every torch / RCCL operation of the pipeline runs on this side stream: work on torch's default (null)
+        # stream waits for whatever is in flight on the library's launch stream (measured: even a .tolist() of
+        # eight numbers takes the length of the running call), a side stream does not
+        self.comm = torch.cuda.Stream(device=device)
+        align_grid_pct = int(os.environ.get("NIMBLE_ALIGN_GRID_PCT", align_grid_pct))
+        for slot in (0, 1):  # leave room beside the persistent align grid for RCCL's kernels
+            lib.device_context(slot).set_option(self.nim.OPT_ALIGN_GRID_PCT, align_grid_pct)
+        self.i = 0
+        self.arrived = None        # (records, key_words, max_len, paired) of batch i-1, exchanged, not yet begun
+        self.inflight = {}         # slot -> shard tensors of the call in flight (kept alive)
+        self._bufs = {}            # re-used device buffers: allocation inside the loop stalls behind the running call
+
+    def _tensor(self, tag, shape, dtype=torch.int64):
+        t = self._bufs.get(tag)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[tag] = t
+        return t
+
+    def _packed(self, tag, n, max_len, paired):
+        pt = self._bufs.get(tag)
+        if pt is None or pt.n != n or pt.max_len != max_len or pt.paired != paired:
+            pt = self.nim.PackedTensors.empty(n, max_len, paired, self.device)
+            self._bufs[tag] = pt
+        return pt
+
+    def _begin(self, b):
+        got, kw, max_len, paired = self.arrived
+        self.arrived = None
+        slot = b % 2
+        shard = self.nim.PackedTensors.unpack(self.util, got, kw, max_len, paired,
+                                              out=self._packed(("shard", b % 3), int(got.shape[0]), max_len, paired))
+        self.lib.score_call_packed_begin(slot, shard)
+        self.inflight[slot] = shard
+
+    def _finish(self, b):
+        slot = b % 2
+        rows = self.lib.score_call_end(slot, raw=True)
+        self.inflight.pop(slot, None)
+        return self.reducer.reduce(rows.keys, rows.counts(), rows.signature())
+
+    def submit(self, r1, r2, n, fixed_len):
+        """Feed batch i; returns the reduced table of batch i-2 (None for the first two calls)."""
+        with torch.cuda.stream(self.comm):
+            return self._submit(r1, r2, n, fixed_len)
+
+    def _submit(self, r1, r2, n, fixed_len):
+        b = self.i
+        t0 = time.perf_counter()
+        pt = self.lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=self.nim.MEM_DEVICE,
+                           device=str(self.device), slot=2, out=self._packed("pack", n, fixed_len, r2 is not None))
+        t1 = time.perf_counter()
+        rec, counts = pt.route(self.util, self.world, out=self._tensor("rec", (n, pt.key_words + 2)))
+        # (the host waited for P(b) only: C(b-1) is not enqueued yet)
+        t2 = time.perf_counter()
+        if self.arrived is not None:
+            self._begin(b - 1)
+        t3 = time.perf_counter()
+        got = exchange_routed(rec, counts, self.group,     # X(b) while C(b-1) runs
+                              alloc=lambda rows: self._tensor(("got", b % 3), (rows, pt.key_words + 2)),
+                              staging=self.reducer.staging)
+        torch.cuda.current_stream().synchronize()
+        t4 = time.perf_counter()
+        self.arrived = (got, pt.key_words, pt.max_len, pt.paired)
+        out = self._finish(b - 2) if b >= 2 else None
+        t5 = time.perf_counter()
+        if _TIMING is not None:
+            for k, v in (("p_pack", t1 - t0), ("p_route_wait", t2 - t1), ("p_begin", t3 - t2), ("p_exchange", t4 - t3),
+                         ("p_finish", t5 - t4)):
+                _TIMING[k] = _TIMING.get(k, 0.0) + v * 1e3
+            _TIMING["steps"] = _TIMING.get("steps", 0) + 1
+        self.i += 1
+        return out
+
+    def flush(self):
+        """Drain: returns the reduced tables of the batches still in the pipeline, oldest first."""
+        with torch.cuda.stream(self.comm):
+            return self._flush()
+
+    def _flush(self):
+        b = self.i
+        outs = []
+        if self.arrived is not None:
+            self._begin(b - 1)
+        if b >= 2:
+            outs.append(self._finish(b - 2))
+        if b >= 1:
+            outs.append(self._finish(b - 1))
+        self.i = 0
+        return outs
 
 
 def sharded_call_packed(lib, r1, r2, n, fixed_len, device, group=None, raw=False):

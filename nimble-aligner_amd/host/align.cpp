@@ -341,13 +341,15 @@ PseudoAligner::CoercionMemo &PseudoAligner::memo_for(const reference_library::Re
 
 nimble_ctx *PseudoAligner::ctx(int slot) {
   if (slot == 0) return ctx_;
-  if (slot != 1) throw Panic("PseudoAligner::ctx: slot must be 0 or 1");
-  if (!ctx2_) check_rc(nimble_ctx_create(index_, nimble_ctx_stream(ctx_), &ctx2_), "nimble_ctx_create");
-  return ctx2_;
+  if (slot != 1 && slot != 2) throw Panic("PseudoAligner::ctx: slot must be 0, 1 or 2");
+  nimble_ctx *&c = extra_[slot - 1];
+  if (!c) check_rc(nimble_ctx_create(index_, nimble_ctx_stream(ctx_), &c), "nimble_ctx_create");
+  return c;
 }
 
 PseudoAligner::~PseudoAligner() {
-  if (ctx2_) nimble_ctx_free(ctx2_);
+  for (nimble_ctx *c : extra_)
+    if (c) nimble_ctx_free(c);
   if (ctx_) nimble_ctx_free(ctx_);
   if (index_) nimble_index_free(index_);
 }
@@ -379,14 +381,20 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
                                const AlignFilterConfig &config, bool want_per_read,
                                std::chrono::steady_clock::time_point t0, int slot = 0);
 
+void begin_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
+                        const AlignFilterConfig &config, int slot) {
+  nimble_align_params p = make_params(config);
+  check_rc(nimble_call_packed(index.ctx(slot), &p, &in, n, max_len), "nimble_call_packed");
+}
+
 void pack_reads(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index, const AlignFilterConfig &config,
-                const nimble_packed &out) {
+                const nimble_packed &out, int slot) {
   if (mates && mates->n != seqs.n)
     throw Panic("Error -- read and reverse read files do not have matching lengths: ");
   nimble_align_params p = make_params(config);
   uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
   if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
-  check_rc(nimble_pack(index.ctx(), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
+  check_rc(nimble_pack(index.ctx(slot), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                        mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,
                        seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST, &out),
            "nimble_pack");

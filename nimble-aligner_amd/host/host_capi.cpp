@@ -141,7 +141,7 @@ void *nimble_library_index(nimble_library *l) { return l->index ? (void *)l->ind
 void *nimble_library_ctx(nimble_library *l) { return l->index ? (void *)l->index->ctx() : nullptr; }
 void *nimble_library_ctx_slot(nimble_library *l, int slot) {
   void *p = nullptr;
-  if (l->index && slot >= 0 && slot <= 1) guarded([&] { p = (void *)l->index->ctx(slot); });
+  if (l->index && slot >= 0 && slot <= 2) guarded([&] { p = (void *)l->index->ctx(slot); });
   return p;
 }
 
@@ -313,6 +313,36 @@ int nimble_library_pack(nimble_library *l, const uint8_t *r1, const uint64_t *r1
     b2.bases = r2;
     b2.offsets = r2_off;
     align::pack_reads(b1, r2 ? &b2 : nullptr, *l->index, l->cfg, *out);
+  });
+}
+
+int nimble_library_pack_slot(nimble_library *l, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
+                             const nimble_packed *out) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_library_pack_slot: the library has no index");
+    align::ReadBatch b1, b2;
+    b1.bases = r1;
+    b1.offsets = r1_off;
+    b1.n = n;
+    b1.fixed_len = fixed_len;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b2.bases = r2;
+    b2.offsets = r2_off;
+    align::pack_reads(b1, r2 ? &b2 : nullptr, *l->index, l->cfg, *out, slot);
+  });
+}
+
+int nimble_score_call_packed_begin(nimble_library *l, int slot, const nimble_packed *in, uint64_t n, uint32_t max_len) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_packed_begin: the library has no index");
+    if (slot < 0 || slot > 1) throw Panic("nimble_score_call_packed_begin: slot must be 0 or 1");
+    if (l->pending[slot]) throw Panic("nimble_score_call_packed_begin: the slot already holds a call (end it first)");
+    align::begin_calls_packed(*in, n, max_len, *l->index, l->cfg, slot);
+    l->pending[slot] = true;
+    l->pending_n[slot] = n;
   });
 }
 

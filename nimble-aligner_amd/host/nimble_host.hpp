@@ -123,7 +123,8 @@ class PseudoAligner {
   ~PseudoAligner();
   nimble_index *index() const { return index_; }
   // slot 0 is the context every call uses; slot 1 (created on first use, same launch stream) lets a second
-  // call be enqueued while the first one's results are read (begin_calls / end_calls)
+  // call be enqueued while the first one's results are read (begin_calls / end_calls); slot 2 is a utility
+  // context for pack / route / unpack while calls are in flight on the other two (multi-GPU pipeline)
   nimble_ctx *ctx(int slot = 0);
   const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
 
@@ -137,7 +138,7 @@ class PseudoAligner {
   PseudoAligner() = default;
   nimble_index *index_ = nullptr;
   nimble_ctx *ctx_ = nullptr;
-  nimble_ctx *ctx2_ = nullptr;
+  nimble_ctx *extra_[2] = {nullptr, nullptr};  // slots 1 and 2
   std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
   std::shared_ptr<CoercionMemo> memo_;
 };
@@ -226,7 +227,10 @@ class CallStream {
 // Split form used by the multi-GPU driver: pack where the reads are, exchange the packed form, run the rest
 // of get_calls on the receiving rank (include/nimble_hip.h: nimble_pack / nimble_call_packed).
 void pack_reads(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
-                const AlignFilterConfig &config, const nimble_packed &out);
+                const AlignFilterConfig &config, const nimble_packed &out, int slot = 0);
+// first half of get_calls_packed (the second half is end_calls on the same slot)
+void begin_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
+                        const AlignFilterConfig &config, int slot);
 CallOutput get_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
                             const reference_library::Reference &reference, const AlignFilterConfig &config);
 

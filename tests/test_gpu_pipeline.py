@@ -422,3 +422,37 @@ def test_device_routing_of_exchange_records(synth_lib, paired):
             for f, c in lib.score_call_packed(shard):
                 merged[tuple(f)] = merged.get(tuple(f), 0) + c
         assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
+
+
+def test_sharded_pipeline_single_rank_rccl(synth_lib, tmp_path):
+    # the pipelined multi-GPU step over real RCCL with one rank: every batch's table equals its direct call,
+    # results come out two submits late and flush() drains the rest
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    nd = importlib.import_module("nimble-aligner_amd.distributed")
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        device = torch.device("cuda", 0)
+        red = nd.TableReducer(device)
+        pipe = nd.ShardedPipeline(lib, device, red)
+        batches = [synth.make_reads(seqs, 20_000 + 1000 * i, seed=700 + i) for i in range(5)]
+        direct = [lib.score_call(b.reshape(-1), None, n=b.shape[0], fixed_len=150) for b in batches]
+        dev = [torch.from_numpy(b.copy()).to(device) for b in batches]
+        torch.cuda.synchronize()
+        outs = []
+        for i, b in enumerate(dev):
+            r = pipe.submit(b, None, b.shape[0], 150)
+            assert (r is None) == (i < 2)
+            if r is not None:
+                outs.append(red.rows(*r))
+        outs += [red.rows(*r) for r in pipe.flush()]
+        assert outs == direct
+        # unpipelined step gives the same
+        assert red.rows(*nd.sharded_step(lib, dev[0], None, batches[0].shape[0], 150, device, red)) == direct[0]
+    finally:
+        dist.destroy_process_group()
