@@ -89,6 +89,7 @@ HIP_SYMBOLS = [
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
     "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
+    "nimble_route_records", "nimble_unpack_records",
 ]
 
 
