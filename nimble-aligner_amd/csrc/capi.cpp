@@ -444,13 +444,27 @@ int finish_call(nimble_ctx *c) {
       HIPCHK(hipMemcpyAsync(sg.data(), c->b_out_seg.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(hipMemcpyAsync(rp.data(), c->b_out_rep.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(hipStreamSynchronize(c->copy_stream));
-      std::vector<uint64_t> order(ne);
-      for (uint64_t i = 0; i < ne; ++i) order[i] = ((uint64_t)a[i] << 32) | b[i];
-      std::vector<uint32_t> idx(ne);
+      // order by (segment, c1, c2): LSD radix sort of the entry indices, 16 bits per pass, skipping constant digits
+      std::vector<uint32_t> idx(ne), tmp(ne);
       for (uint64_t i = 0; i < ne; ++i) idx[i] = (uint32_t)i;
-      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
-        return sg[x] != sg[y] ? sg[x] < sg[y] : order[x] < order[y];
-      });
+      const std::vector<uint32_t> *cols[3] = {&b, &a, &sg};  // least significant first
+      std::vector<uint32_t> hist(65536);
+      for (int col = 0; col < 3; ++col) {
+        const std::vector<uint32_t> &v = *cols[col];
+        for (int shift = 0; shift < 32; shift += 16) {
+          std::fill(hist.begin(), hist.end(), 0u);
+          for (uint64_t i = 0; i < ne; ++i) hist[(v[i] >> shift) & 0xFFFFu]++;
+          if (hist[(v[0] >> shift) & 0xFFFFu] == ne) continue;  // every entry has the same digit
+          uint32_t run = 0;
+          for (uint32_t d = 0; d < 65536; ++d) {
+            const uint32_t c0 = hist[d];
+            hist[d] = run;
+            run += c0;
+          }
+          for (uint64_t i = 0; i < ne; ++i) tmp[hist[(v[idx[i]] >> shift) & 0xFFFFu]++] = idx[i];
+          idx.swap(tmp);
+        }
+      }
       for (uint64_t i = 0; i < ne; ++i) {
         c->h_c1[i] = a[idx[i]];
         c->h_c2[i] = b[idx[i]];

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <unordered_set>
 
 #include "../../include/nimble_hip.h"
@@ -296,6 +297,43 @@ std::unique_ptr<PseudoAligner> PseudoAligner::build_index(const std::vector<std:
   return pa;
 }
 
+// open-addressing map u64 -> i32 (class pair -> callset id); ~0 never occurs as a key (a pair has at least one class)
+struct FlatMap64 {
+  std::vector<uint64_t> keys;
+  std::vector<int32_t> vals;
+  size_t used = 0;
+  FlatMap64() : keys(1u << 12, ~0ULL), vals(1u << 12, 0) {}
+  static uint64_t mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    return x;
+  }
+  const int32_t *find(uint64_t k) const {
+    const size_t mask = keys.size() - 1;
+    for (size_t p = (size_t)mix(k) & mask;; p = (p + 1) & mask) {
+      if (keys[p] == k) return &vals[p];
+      if (keys[p] == ~0ULL) return nullptr;
+    }
+  }
+  void insert(uint64_t k, int32_t v) {
+    if ((used + 1) * 2 > keys.size()) {
+      FlatMap64 big;
+      big.keys.assign(keys.size() * 2, ~0ULL);
+      big.vals.assign(keys.size() * 2, 0);
+      for (size_t i = 0; i < keys.size(); ++i)
+        if (keys[i] != ~0ULL) big.insert(keys[i], vals[i]);
+      *this = std::move(big);
+    }
+    const size_t mask = keys.size() - 1;
+    size_t p = (size_t)mix(k) & mask;
+    while (keys[p] != ~0ULL && keys[p] != k) p = (p + 1) & mask;
+    if (keys[p] == ~0ULL) ++used;
+    keys[p] = k;
+    vals[p] = v;
+  }
+};
+
 struct PseudoAligner::CoercionMemo {
   // exact copies of everything Coercer reads
   size_t group_on = 0, name_idx = 0;
@@ -306,7 +344,8 @@ struct PseudoAligner::CoercionMemo {
   size_t discard_multi_hits = 0, max_hits = 0;
   std::unique_ptr<Coercer> coercer;
   // (class R1 << 32 | class R2) -> index into `callsets` (or -1 when the pair is triaged away)
-  std::unordered_map<uint64_t, int32_t> pairs;
+  FlatMap64 pairs;
+  std::deque<std::string> joined;  // callsets joined by '\t', by callset id (stable addresses)
   std::unordered_map<uint64_t, FilterReason> pair_triage;  // why a pair with id -1 was dropped (align.rs:228-239,776)
   std::vector<std::vector<std::string>> callsets;
   std::map<std::vector<std::string>, int32_t> callset_ids;
@@ -362,6 +401,29 @@ const std::vector<uint32_t> &PseudoAligner::eq_class(uint32_t id) {
   std::vector<uint32_t> v(len);
   if (len) check_rc(nimble_class_get(index_, id, v.data(), len, &len), "nimble_class_get");
   return class_cache_.emplace(id, std::move(v)).first->second;
+}
+
+const std::vector<std::string> &RowRefs::features(size_t i) const { return memo->callsets.at((size_t)ids.at(i)); }
+
+const std::string &RowRefs::joined(size_t i) const {
+  PseudoAligner::CoercionMemo &m = *memo;
+  while (m.joined.size() < m.callsets.size()) {
+    const std::vector<std::string> &f = m.callsets[m.joined.size()];
+    std::string j;
+    for (size_t k = 0; k < f.size(); ++k) {
+      if (k) j.push_back('\t');
+      j += f[k];
+    }
+    m.joined.push_back(std::move(j));
+  }
+  return m.joined[(size_t)ids.at(i)];
+}
+
+void CallOutput::materialize() {
+  if (rows.size() == refs.size()) return;
+  rows.clear();
+  rows.reserve(refs.size());
+  for (size_t i = 0; i < refs.size(); ++i) rows.emplace_back(refs.features(i), refs.counts[i]);
 }
 
 static nimble_align_params make_params(const AlignFilterConfig &config) {
@@ -483,13 +545,16 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
   memo.counts.assign(memo.callsets.size(), 0);
   for (uint64_t e = 0; e < ne; ++e) {
     const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
-    auto it = memo.pairs.find(key);
-    if (it == memo.pairs.end()) {
+    const int32_t *hit = memo.pairs.find(key);
+    int32_t id;
+    if (hit) {
+      id = *hit;
+    } else {
       bool has1 = c1[e] != NIMBLE_CLASS_NONE, has2 = c2[e] != NIMBLE_CLASS_NONE;
       FilterReason triage;
       std::vector<std::string> callset = memo.coercer->coerce(has1, has1 ? index.eq_class(c1[e]) : empty, has2,
                                                               has2 ? index.eq_class(c2[e]) : empty, triage);
-      int32_t id = -1;
+      id = -1;
       if (!callset.empty()) {
         auto ins = memo.callset_ids.emplace(callset, (int32_t)memo.callsets.size());
         if (ins.second) {
@@ -500,9 +565,9 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
         id = ins.first->second;
       }
       if (id < 0) memo.pair_triage[key] = triage;
-      it = memo.pairs.emplace(key, id).first;
+      memo.pairs.insert(key, id);
     }
-    if (it->second >= 0) memo.counts[(size_t)it->second] += (int64_t)cnt[e];
+    if (id >= 0) memo.counts[(size_t)id] += (int64_t)cnt[e];
   }
   auto t3 = now();
   if (memo.sorted.size() != memo.callsets.size()) {
@@ -510,8 +575,13 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
     for (auto &kv : memo.callset_ids) memo.sorted.push_back(kv.second);  // std::map order == Vec<String> order
   }
   CallOutput out;
+  out.refs.memo = index.memo_ptr();
   for (int32_t id : memo.sorted)
-    if (memo.counts[(size_t)id]) out.rows.emplace_back(memo.callsets[(size_t)id], (int32_t)memo.counts[(size_t)id]);
+    if (memo.counts[(size_t)id]) {
+      out.refs.ids.push_back(id);
+      out.refs.counts.push_back((int32_t)memo.counts[(size_t)id]);
+    }
+  if (!index.light_rows()) out.materialize();
   if (timing) {
     auto t4 = now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -578,8 +648,7 @@ UmiOutput get_calls_umis(const ReadBatch &seqs, const ReadBatch *mates, const Um
   static const std::vector<uint32_t> empty;
   auto callset_of = [&](uint32_t a, uint32_t b) -> int32_t {
     const uint64_t key = ((uint64_t)a << 32) | b;
-    auto it = memo.pairs.find(key);
-    if (it != memo.pairs.end()) return it->second;
+    if (const int32_t *hit = memo.pairs.find(key)) return *hit;
     const bool has1 = a != NIMBLE_CLASS_NONE, has2 = b != NIMBLE_CLASS_NONE;
     FilterReason triage;
     std::vector<std::string> callset =
@@ -596,7 +665,7 @@ UmiOutput get_calls_umis(const ReadBatch &seqs, const ReadBatch *mates, const Um
     } else {
       memo.pair_triage[key] = triage;
     }
-    memo.pairs.emplace(key, id);
+    memo.pairs.insert(key, id);
     return id;
   };
   UmiOutput out;
@@ -704,6 +773,7 @@ align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch
                        const align::AlignFilterConfig &aligner_config, bool want_per_read) {
   align::CallOutput out = align::get_calls(sequences, mate_sequences, reference_index, reference, aligner_config,
                                            want_per_read);
+  out.materialize();
   // utils::sort_score_vector (utils.rs:54-59): Vec<String> ordering, byte-wise per string
   std::sort(out.rows.begin(), out.rows.end(),
             [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
@@ -714,6 +784,7 @@ align::CallOutput call_packed(const nimble_packed &in, uint64_t n, uint32_t max_
                               align::PseudoAligner &reference_index, const reference_library::Reference &reference,
                               const align::AlignFilterConfig &aligner_config) {
   align::CallOutput out = align::get_calls_packed(in, n, max_len, reference_index, reference, aligner_config);
+  out.materialize();
   std::sort(out.rows.begin(), out.rows.end(),
             [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
   return out;

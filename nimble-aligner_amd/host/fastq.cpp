@@ -319,6 +319,7 @@ void streamed(const std::vector<std::string> &input_files,
   }
   for (size_t i = 0; i < streams.size(); ++i) {
     align::CallOutput res = streams[i]->finish(references.at(i));
+    res.materialize();
     std::sort(res.rows.begin(), res.rows.end(),
               [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
     utils::write_to_tsv(res.rows, output_paths.at(i));

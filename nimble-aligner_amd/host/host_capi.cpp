@@ -45,8 +45,7 @@ struct nimble_umi_rows {
   std::vector<std::string> joined;
 };
 struct nimble_rows {
-  std::vector<align::ScoreRow> rows;
-  std::vector<std::string> joined;
+  align::CallOutput out;  // refs only (the index runs in light mode): no per-call string copies
 };
 
 extern "C" {
@@ -135,6 +134,7 @@ int nimble_library_build_index(nimble_library *l, int device) {
   return guarded([&] {
     auto data = utils::get_reference_sequence_data(l->ref);
     l->index = align::PseudoAligner::build_index(data.first, data.second, device);
+    l->index->set_light_rows(true);
   });
 }
 void *nimble_library_index(nimble_library *l) { return l->index ? (void *)l->index->index() : nullptr; }
@@ -147,8 +147,7 @@ void *nimble_library_ctx_slot(nimble_library *l, int slot) {
 
 static nimble_rows *make_rows(align::CallOutput &&o) {
   nimble_rows *r = new nimble_rows();
-  r->rows = std::move(o.rows);
-  for (auto &row : r->rows) r->joined.push_back(join_tab(row.first));
+  r->out = std::move(o);
   return r;
 }
 
@@ -168,7 +167,8 @@ int nimble_score_call(nimble_library *l, const uint8_t *r1, const uint64_t *r1_o
     b2 = b1;
     b2.bases = r2;
     b2.offsets = r2_off;
-    *out = make_rows(score::call(b1, r2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
+    // rows come back as references in Vec<String> order (the order of utils::sort_score_vector)
+    *out = make_rows(align::get_calls(b1, r2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
   });
 }
 
@@ -200,10 +200,7 @@ int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
     if (!l->index) throw Panic("nimble_score_call_end: the library has no index");
     if (slot < 0 || slot > 1 || !l->pending[slot]) throw Panic("nimble_score_call_end: no call was begun in this slot");
     l->pending[slot] = false;
-    align::CallOutput o = align::end_calls(l->pending_n[slot], *l->index, l->ref, l->cfg, slot);
-    std::sort(o.rows.begin(), o.rows.end(),
-              [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
-    *out = make_rows(std::move(o));
+    *out = make_rows(align::end_calls(l->pending_n[slot], *l->index, l->ref, l->cfg, slot));
   });
 }
 
@@ -290,10 +287,7 @@ int nimble_score_stream_end(nimble_library *l, nimble_rows **out) {
   return guarded([&] {
     if (!l->stream) throw Panic("nimble_score_stream_end: no stream is open");
     std::unique_ptr<align::CallStream> st = std::move(l->stream);
-    align::CallOutput o = st->finish(l->ref);
-    std::sort(o.rows.begin(), o.rows.end(),
-              [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
-    *out = make_rows(std::move(o));
+    *out = make_rows(st->finish(l->ref));
   });
 }
 
@@ -351,7 +345,7 @@ int nimble_score_call_packed(nimble_library *l, const nimble_packed *in, uint64_
   *out = nullptr;
   return guarded([&] {
     if (!l->index) throw Panic("nimble_score_call_packed: the library has no index");
-    *out = make_rows(score::call_packed(*in, n, max_len, *l->index, l->ref, l->cfg));
+    *out = make_rows(align::get_calls_packed(*in, n, max_len, *l->index, l->ref, l->cfg));
   });
 }
 
@@ -373,26 +367,24 @@ int nimble_score_call_fastq(nimble_library *l, const char *p1, const char *p2, n
       b2.n = d1.n();
       b2.max_len = d2.max_len;
     }
-    *out = make_rows(score::call(b1, p2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
+    *out = make_rows(align::get_calls(b1, p2 ? &b2 : nullptr, *l->index, l->ref, l->cfg));
   });
 }
 
 void nimble_rows_free(nimble_rows *r) { delete r; }
 uint64_t nimble_rows_signature(const nimble_rows *r) {
-  uint64_t h = 1469598103934665603ULL ^ (uint64_t)r->joined.size();
-  for (const std::string &s : r->joined) {
-    for (unsigned char ch : s) h = (h ^ ch) * 1099511628211ULL;
-    h = (h ^ 0xFFu) * 1099511628211ULL;
-  }
-  return h;
+  // the callset ids index the index's memo, which only ever appends: equal id lists = equal keys in equal order
+  uint64_t h = 1469598103934665603ULL ^ (uint64_t)r->out.refs.size();
+  for (int32_t id : r->out.refs.ids) h = (h ^ (uint64_t)(uint32_t)id) * 1099511628211ULL;
+  return h ^ (uint64_t)(uintptr_t)r->out.refs.memo.get();
 }
 void nimble_rows_counts(const nimble_rows *r, int64_t *out) {
-  for (size_t i = 0; i < r->rows.size(); ++i) out[i] = r->rows[i].second;
+  for (size_t i = 0; i < r->out.refs.size(); ++i) out[i] = r->out.refs.counts[i];
 }
-uint64_t nimble_rows_count(const nimble_rows *r) { return r->rows.size(); }
+uint64_t nimble_rows_count(const nimble_rows *r) { return r->out.refs.size(); }
 const char *nimble_rows_get(const nimble_rows *r, uint64_t i, int32_t *count) {
-  *count = r->rows.at(i).second;
-  return r->joined.at(i).c_str();
+  *count = r->out.refs.counts.at(i);
+  return r->out.refs.joined(i).c_str();
 }
 
 int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, nimble_library *const *libs,
@@ -421,7 +413,12 @@ int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, ni
 }
 
 int nimble_write_to_tsv(const nimble_rows *r, const char *path) {
-  return guarded([&] { utils::write_to_tsv(r->rows, path); });
+  return guarded([&] {
+    align::CallOutput copy;
+    copy.refs = r->out.refs;
+    copy.materialize();
+    utils::write_to_tsv(copy.rows, path);
+  });
 }
 
 int nimble_host_coerce(const nimble_library *l, int has1, const uint32_t *c1, int n1, int has2, const uint32_t *c2,

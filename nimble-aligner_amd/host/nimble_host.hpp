@@ -133,6 +133,11 @@ class PseudoAligner {
   // copy of those inputs and is dropped as soon as a call arrives with different ones.
   struct CoercionMemo;
   CoercionMemo &memo_for(const reference_library::Reference &reference, const AlignFilterConfig &config);
+  std::shared_ptr<CoercionMemo> memo_ptr() const { return memo_; }
+  // light mode: calls return RowRefs only (no per-call copies of the callset strings); CallOutput::materialize()
+  // builds the owning rows on demand.  The C ABI runs the index in light mode.
+  void set_light_rows(bool on) { light_rows_ = on; }
+  bool light_rows() const { return light_rows_; }
 
  private:
   PseudoAligner() = default;
@@ -141,6 +146,7 @@ class PseudoAligner {
   nimble_ctx *extra_[2] = {nullptr, nullptr};  // slots 1 and 2
   std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
   std::shared_ptr<CoercionMemo> memo_;
+  bool light_rows_ = false;
 };
 
 // A batch of reads in memory: concatenated ASCII bases + n+1 offsets (what the reference's boxed
@@ -163,10 +169,22 @@ struct FilterRecord {  // value of the filter_reasons map, src/align.rs:408
   FilterReason triage;
 };
 
+// The rows of one call without a string copy: callset ids into the index's coercion memo (which keeps every
+// callset it has produced, and its '\t'-joined form) in Vec<String> order, and the counts.
+struct RowRefs {
+  std::shared_ptr<PseudoAligner::CoercionMemo> memo;
+  std::vector<int32_t> ids, counts;
+  size_t size() const { return ids.size(); }
+  const std::vector<std::string> &features(size_t i) const;
+  const std::string &joined(size_t i) const;
+};
+
 struct CallOutput {
-  std::vector<ScoreRow> rows;  // unsorted from get_calls, sorted from score::call
+  std::vector<ScoreRow> rows;  // in Vec<String> order; empty until materialize() when the index is in light mode
+  RowRefs refs;                // always filled
   // filled only when requested: read index -> reasons (the reference keys this by read string)
   std::vector<FilterRecord> per_read;
+  void materialize();          // rows from refs (idempotent)
 };
 
 // align::get_calls (src/align.rs:392-467).  mates == nullptr for single-end.
