@@ -38,7 +38,8 @@ def main():
                          "exchange with the previous call)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU step (route, all-to-all, reduce over RCCL) even with one rank")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
+                    help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
     args = ap.parse_args()
 
@@ -249,7 +250,7 @@ def main():
             t1 = time.perf_counter()
             ores = ora.call(oidx, ref, cfg, sample.reshape(-1), offs, n_threads=threads)
             cpu_s = time.perf_counter() - t1
-            S1 = min(S, 200_000)
+            S1 = min(S, 1_000_000)
             t1 = time.perf_counter()
             ora.call(oidx, ref, cfg, sample[:S1].reshape(-1), synth.fixed_offsets(S1, L), n_threads=1)
             cpu1_s = time.perf_counter() - t1
