@@ -202,7 +202,11 @@ class Index:
             hip_lib().nimble_index_free(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may be gone already
+            self.close()
+        except Exception:
+            pass
 
     def stats(self):
         s = (C.c_uint64 * 8)()
@@ -243,7 +247,11 @@ class Context:
             hip_lib().nimble_ctx_free(self.h)
         self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may be gone already
+            self.close()
+        except Exception:
+            pass
 
     def call(self, params, r1, r1_off=None, r2=None, r2_off=None, n=None, fixed_len=0, max_len=0, mem=MEM_HOST):
         """nimble_call.  r1/r2: numpy uint8 arrays (host) or torch uint8 tensors / raw pointers (device)."""
@@ -641,7 +649,11 @@ class RowsHandle:
             host_lib().nimble_rows_free(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may be gone already
+            self.close()
+        except Exception:
+            pass
 
 
 class Library:
@@ -661,7 +673,11 @@ class Library:
             host_lib().nimble_library_free(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may be gone already
+            self.close()
+        except Exception:
+            pass
 
     @property
     def config(self):
