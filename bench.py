@@ -220,6 +220,20 @@ def main():
                     traffic = tj.get("k_align_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # measured device stream copy on this box: read + write of 1 GiB, best of 5
+        a_ = torch.empty(1 << 27, dtype=torch.int64, device=device)
+        b_ = torch.empty_like(a_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        copy_ms = None
+        for _ in range(5):
+            e0.record()
+            b_.copy_(a_)
+            e1.record()
+            e1.synchronize()
+            t_ = e0.elapsed_time(e1)
+            copy_ms = t_ if copy_ms is None else min(copy_ms, t_)
+        stream_copy_gbps = 2 * a_.numel() * 8 / (copy_ms / 1e3) / 1e9
+        del a_, b_
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "k_align",
@@ -235,6 +249,8 @@ def main():
                          "achieved_GBps": pipe_bytes / (stage["total"] / 1000.0) / 1e9,
                          "frac": pipe_bytes / (stage["total"] / 1000.0) / 1e9 / HBM_PEAK_GBPS},
             "counters": {"probes": P, "nodes": U, "class_entries": E, "seeded": hit},
+            "stream_copy_GBps": stream_copy_gbps,
+            "frac_of_stream_copy": align_bytes / align_s / 1e9 / stream_copy_gbps,
         }
         # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same reads
         if args.cpu_sample > 0:
