@@ -770,8 +770,9 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
                       const nimble_packed *ext) {
   const int nm = paired ? 2 : 1;
   const uint32_t kw = (max_len * (uint32_t)nm + 31u) / 32u;
-  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 > 64 * 1024)
-    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~900)");
+  // the walk keeps every key of a tile in LDS; one workgroup may take up to 160 KiB on gfx950
+  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 > 160 * 1024)
+    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~2400)");
   if (ext && ext->key_words != kw) return fail(NIMBLE_E_INVALID, "packed buffers: key_words does not match max_len");
   CallBuffers &cb = c->cb;
   cb.n = n;
@@ -808,7 +809,8 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   c->scratch_cap = std::min<uint64_t>(std::max<uint64_t>(c->scratch_cap, env_u64("NIMBLE_SCRATCH_PER_READ", 4) * n),
                                       0xFFFFFF00ULL);
   need(c->b_scratch, c->scratch_cap * 4);
-  const uint32_t ws_rows = max_len > align_lds_cols() ? max_len - align_lds_cols() : 0;
+  // spill area of the visited-colour lists: only an index with classes outside the 64-row mask form keeps lists
+  const uint32_t ws_rows = (!c->ix->dev.all_local && max_len > align_lds_cols()) ? max_len - align_lds_cols() : 0;
   need(c->b_ws, std::max<size_t>((size_t)ws_rows * align_ws_lanes() * 4, 16));
   const uint64_t dslots = std::max<uint64_t>(n + n / 2, 1024);  // load factor <= 2/3 even if every read is kept
   {

@@ -1323,12 +1323,18 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter
-  static int resident_cache[64] = {0};
-  int key = (int)(lds / 2048) & 63;
+  static int resident_cache[128] = {0};
+  int key = (int)(lds / 2048) & 127;
   if (resident_cache[key] == 0) {
     int per_cu = 0, dev = 0, cus = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (lds > 48 * 1024) {  // long reads: opt in to more dynamic LDS than the default limit
+      (void)hipFuncSetAttribute((const void *)k_align<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)k_align<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)k_align<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)k_align<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align<true, true>, ALIGN_BLOCK, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 4;

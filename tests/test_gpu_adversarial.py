@@ -1,0 +1,123 @@
+"""GPU parity on inputs chosen to break things: repetitive and cyclic libraries (the unitig construction and the
+walk have to agree with the oracle where k-mers repeat), homopolymers, identical and reverse-complement-palindromic
+features, reads at the maximum supported length, the discard_* filters, and calls that are one key repeated."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+from test_gpu_parity import Case, make_cfg, nim, params_from, synth
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rnd(rng, k):
+    return ACGT[rng.integers(0, 4, size=k)].tobytes().decode()
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def sample_reads(rng, seqs, n, L, err=0.3, junk=0.05):
+    reads = []
+    for _ in range(n):
+        f = int(rng.integers(0, len(seqs)))
+        s = seqs[f]
+        if len(s) <= L or rng.random() < junk:
+            reads.append(rnd(rng, L).encode())
+            continue
+        st = int(rng.integers(0, len(s) - L))
+        r = np.frombuffer(s[st:st + L].encode(), dtype=np.uint8).copy()
+        if rng.random() < 0.5:
+            r = np.frombuffer(revcomp(r.tobytes().decode()).encode(), dtype=np.uint8).copy()
+        if rng.random() < err:
+            for _ in range(int(rng.integers(1, 4))):
+                r[int(rng.integers(0, L))] = ACGT[int(rng.integers(0, 4))]
+        reads.append(r.tobytes())
+    return reads
+
+
+def test_repeats_cycles_and_homopolymers():
+    rng = np.random.default_rng(101)
+    unit = rnd(rng, 37)
+    names, seqs = [], []
+    seqs.append(rnd(rng, 120) + unit * 9 + rnd(rng, 150))            # tandem repeat longer than k: k-mer cycle
+    seqs.append(rnd(rng, 80) + unit * 4 + rnd(rng, 200))             # the same unit elsewhere
+    seqs.append("A" * 90 + rnd(rng, 200) + "T" * 70)                 # homopolymer runs: self-loop k-mers
+    seqs.append(rnd(rng, 100) + "AC" * 60 + rnd(rng, 100))           # period-2 repeat
+    pal = rnd(rng, 75)
+    seqs.append(pal + revcomp(pal) + rnd(rng, 120))                  # reverse-complement palindrome
+    seqs.append(seqs[0])                                              # an identical feature
+    seqs.append(seqs[1][:200])                                        # a prefix of another feature
+    core = rnd(rng, 400)
+    seqs += [core[:200] + rnd(rng, 3) + core[203:] for _ in range(6)]  # near-identical alleles
+    seqs.append((unit * 3)[:100])                                     # the bare repeat (exactly 100 bases)
+    seqs.append(rnd(rng, 29))                                         # shorter than k: contributes no k-mer
+    seqs.append(rnd(rng, 30))                                         # exactly one k-mer
+    names = ["R%02d" % i for i in range(len(seqs))]
+    case = Case(names, seqs, make_cfg(score_percent=0.1, score_threshold=20, max_hits_to_report=50))
+    assert case.dindex.stats()["kmers"] == case.oindex.stats()["kmers"]
+    assert case.dindex.stats()["nodes"] == case.oindex.stats()["nodes"]
+    reads = sample_reads(rng, seqs, 8000, 150)
+    reads += [(unit * 5)[:150].encode(), ("A" * 150).encode(), ("AC" * 75).encode(), (pal + revcomp(pal)).encode()]
+    reads += [seqs[-1].encode() + b"ACGT" * 5, b"ACGT" * 5 + seqs[-1].encode() + rnd(rng, 60).encode()]
+    b, o = ora.pack_reads(reads)
+    for nm in (0, 1, 5):
+        case.check(b, o, cfg=case.cfg.copy(num_mismatches=nm))
+    # paired, with every pair filter
+    r2 = [revcomp(r.decode().upper().replace("N", "A")).encode() if i % 2 else r for i, r in enumerate(reads)]
+    b2, o2 = ora.pack_reads(r2)
+    for valid in (0, 1):
+        case.check(b, o, b2, o2, cfg=case.cfg.copy(num_mismatches=2, require_valid_pair=valid))
+
+
+def test_maximum_read_length_single_and_paired():
+    rng = np.random.default_rng(202)
+    seqs = [rnd(rng, int(rng.integers(2500, 5000))) for _ in range(40)]
+    seqs += [seqs[i][:600] + rnd(rng, 5) + seqs[i][605:] for i in range(10)]
+    names = ["L%02d" % i for i in range(len(seqs))]
+    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=50))
+    reads = sample_reads(rng, seqs, 1500, 2380, err=0.6)          # max_len * mates must stay below ~2400
+    reads += sample_reads(rng, seqs, 1500, 880, err=0.6)
+    b, o = ora.pack_reads(reads)
+    case.check(b, o, cfg=case.cfg.copy(num_mismatches=3))
+    r1 = sample_reads(rng, seqs, 1500, 1190, err=0.5)
+    r2 = sample_reads(rng, seqs, 1500, 1187, err=0.5)
+    b1, o1 = ora.pack_reads(r1)
+    b2, o2 = ora.pack_reads(r2)
+    case.check(b1, o1, b2, o2, cfg=case.cfg.copy(num_mismatches=2))
+    with pytest.raises(nim.NimbleError, match="too long"):
+        big = [rnd(rng, 3000).encode()]
+        bb, oo = ora.pack_reads(big)
+        case.ctx.call(params_from(case.cfg), bb, oo)
+
+
+@pytest.mark.parametrize("flag", ["discard_multiple_matches", "discard_nonzero_mismatch"])
+def test_discard_filters(flag):
+    names, seqs = synth.make_library(60)
+    case = Case(names, seqs, make_cfg(score_percent=0.1, score_threshold=20))
+    reads = synth.make_reads(seqs, 20000, seed=7)
+    o = synth.fixed_offsets(reads.shape[0], 150)
+    cfg = case.cfg.copy(num_mismatches=2, **{flag: 1})
+    res = case.check(reads.reshape(-1), o, cfg=cfg)
+    want = 1 if flag == "discard_multiple_matches" else 2
+    assert int((res.per_read["reason"][0] == want).sum()) > 100      # the filter really fires
+
+
+def test_one_key_repeated_and_all_filtered():
+    names, seqs = synth.make_library(20)
+    case = Case(names, seqs, make_cfg())
+    one = np.frombuffer(seqs[3][50:200].upper().encode(), dtype=np.uint8)
+    reads = np.tile(one, (200_000, 1))                                # 200 k copies of one key: one count
+    o = synth.fixed_offsets(reads.shape[0], 150)
+    res = case.check(reads.reshape(-1), o)
+    assert res.counters["unique_keys"] == 1 and int(res.per_read["counted"].sum()) == 1
+    assert res.per_read["counted"][-1] == 1                           # the last writer represents the key
+    junk = synth.ACGT[np.random.default_rng(1).integers(0, 4, size=(50_000, 150), dtype=np.uint8)]
+    res = case.check(junk.reshape(-1), synth.fixed_offsets(50_000, 150))
+    assert res.rows == [] and res.counters["unique_keys"] == 0
+    short = np.tile(one[:39], (1000, 1))                              # everything ShortRead
+    res = case.check(short.reshape(-1), synth.fixed_offsets(1000, 39))
+    assert (res.per_read["reason"][0] == 8).all()
