@@ -303,14 +303,12 @@ int enqueue_compact(nimble_ctx *c) {
 int enqueue_head(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
-  const size_t nn = std::max<uint64_t>(cb.n, 1);
   HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   c->dedup_clean_slots = 0;
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
   if (cb.hist_rep) HIPCHK(hipMemsetAsync(cb.hist_rep, 0, c->hist_slots * 4, s));
-  if (!cb.paired) HIPCHK(hipMemsetAsync(cb.len[1], 0, nn * 4, s));
   HIPCHK(hipEventRecord(c->ev[0], s));
   return NIMBLE_OK;
 }
@@ -818,7 +816,8 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
     need(c->b_dedup, dslots * 8);
     if (c->b_dedup.p != before) c->dedup_clean_slots = 0;
   }
-  if (c->hist_slots == 0) c->hist_slots = pow2_at_least(env_u64("NIMBLE_HIST_SLOTS", 1ULL << 20));
+  // (class pair) histogram: 256 k slots to start with (a 10 M-read call has 5-40 k entries); grows 16x on overflow
+  if (c->hist_slots == 0) c->hist_slots = pow2_at_least(env_u64("NIMBLE_HIST_SLOTS", 1ULL << 18));
   need(c->b_hist_keys, c->hist_slots * 8);
   need(c->b_hist_cnt, c->hist_slots * 8);
   need(c->b_state, 16 * 8);
