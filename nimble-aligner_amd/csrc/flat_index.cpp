@@ -10,7 +10,12 @@
 #include "flat_index.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 namespace nimble {
@@ -24,9 +29,61 @@ struct Occ {
 
 inline int popc4(uint32_t m) { return __builtin_popcount(m & 0xF); }
 
+// NIMBLE_INDEX_TIMING=1: phase times of the build on stderr
+struct PhaseTimer {
+  bool on = getenv("NIMBLE_INDEX_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[nimble index] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
+unsigned build_threads() {
+  if (const char *e = getenv("NIMBLE_INDEX_THREADS")) return (unsigned)std::max(1, atoi(e));
+  unsigned h = std::thread::hardware_concurrency();
+  return h == 0 ? 1u : std::min(h, 32u);
+}
+
+// fn(t) on `threads` threads
+template <class F>
+void parallel_threads(unsigned threads, F fn) {
+  if (threads <= 1) {
+    fn(0u);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(threads);
+  for (unsigned t = 0; t < threads; ++t)
+    th.emplace_back([&, t] {
+      try {
+        fn(t);
+      } catch (...) {
+        err[t] = std::current_exception();
+      }
+    });
+  for (auto &x : th) x.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+// fn(t, lo, hi) over [0, n) in `threads` contiguous slices (slice t = [n t / threads, n (t+1) / threads))
+template <class F>
+void parallel_slices(size_t n, unsigned threads, F fn) {
+  if (threads <= 1 || n < 4096) {
+    fn(0u, (size_t)0, n);
+    return;
+  }
+  parallel_threads(threads, [&](unsigned t) { fn(t, n * t / threads, n * (t + 1) / threads); });
+}
+
 }  // namespace
 
 void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs, FlatIndex &out) {
+  PhaseTimer timer;
+  const unsigned threads = build_threads();
   // 1. all k-mer occurrences
   uint64_t total = 0;
   for (uint32_t s = 0; s < n_seqs; ++s) {
@@ -48,8 +105,45 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
       occ.push_back(Occ{km, s, l | (r << 4)});
     }
   }
-  std::sort(occ.begin(), occ.end(),
-            [](const Occ &a, const Occ &b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
+  timer.lap("k-mer occurrences");
+  {
+    // sort by (k-mer, row): 256 buckets on the top k-mer bits, filled and then sorted by the worker threads
+    auto less = [](const Occ &a, const Occ &b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; };
+    if (threads <= 1 || occ.size() < (1u << 16)) {
+      std::sort(occ.begin(), occ.end(), less);
+    } else {
+      constexpr unsigned NB = 256, SH = 2 * KMER - 8;
+      std::vector<std::vector<uint64_t>> cnt(threads, std::vector<uint64_t>(NB, 0));
+      parallel_slices(occ.size(), threads, [&](unsigned t, size_t lo, size_t hi) {
+        std::vector<uint64_t> &c = cnt[t];
+        for (size_t i = lo; i < hi; ++i) c[occ[i].kmer >> SH]++;
+      });
+      // bucket starts, and inside a bucket one range per slice (slices in order: the fill is deterministic)
+      std::vector<uint64_t> start(NB + 1, 0);
+      for (unsigned b = 0; b < NB; ++b) {
+        uint64_t run = start[b];
+        for (unsigned t = 0; t < threads; ++t) {
+          const uint64_t c = cnt[t][b];
+          cnt[t][b] = run;
+          run += c;
+        }
+        start[b + 1] = run;
+      }
+      std::vector<Occ> tmp(occ.size());
+      parallel_slices(occ.size(), threads, [&](unsigned t, size_t lo, size_t hi) {
+        std::vector<uint64_t> &c = cnt[t];
+        for (size_t i = lo; i < hi; ++i) tmp[c[occ[i].kmer >> SH]++] = occ[i];
+      });
+      occ.swap(tmp);
+      std::vector<Occ>().swap(tmp);
+      std::atomic<unsigned> nextb{0};
+      parallel_threads(threads, [&](unsigned) {
+        for (unsigned b = nextb++; b < NB; b = nextb++)
+          std::sort(occ.begin() + (long)start[b], occ.begin() + (long)start[b + 1], less);
+      });
+    }
+  }
+  timer.lap("sort");
 
   // 2. distinct k-mers, their extension masks and colour classes (interned by content)
   std::vector<uint64_t> kmers;
@@ -93,6 +187,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     i = j;
   }
   std::vector<Occ>().swap(occ);
+  timer.lap("distinct k-mers + colours");
   const size_t n = kmers.size();
   out.n_kmers = n;
   out.n_colours = out.col_off.size() - 1;
@@ -106,15 +201,19 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   // 3. join relation next[]/prev[] (UINT32_MAX = none)
   if (n >= UINT32_MAX) throw std::runtime_error("index build: too many k-mers");
   std::vector<uint32_t> next(n, UINT32_MAX), prev(n, UINT32_MAX);
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t r = exts[i] >> 4;
-    if (popc4(r) != 1) continue;
-    uint64_t nk = ((kmers[i] << 2) | (uint64_t)__builtin_ctz(r)) & KMER_MASK;
-    size_t j = find(nk);
-    if (popc4(exts[j] & 0xF) != 1 || colour[j] != colour[i]) continue;
-    next[i] = (uint32_t)j;
-    prev[j] = (uint32_t)i;
-  }
+  // (a k-mer with one left extension has one predecessor: no two i write the same prev[j])
+  parallel_slices(n, threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      uint32_t r = exts[i] >> 4;
+      if (popc4(r) != 1) continue;
+      uint64_t nk = ((kmers[i] << 2) | (uint64_t)__builtin_ctz(r)) & KMER_MASK;
+      size_t j = find(nk);
+      if (popc4(exts[j] & 0xF) != 1 || colour[j] != colour[i]) continue;
+      next[i] = (uint32_t)j;
+      prev[j] = (uint32_t)i;
+    }
+  });
+  timer.lap("join relation");
   // cut pure cycles in front of their smallest k-mer: walk chains from heads first, then leftovers
   std::vector<uint8_t> seen(n, 0);
   std::vector<uint32_t> heads;
@@ -133,23 +232,30 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     }
   std::sort(heads.begin(), heads.end());
 
+  timer.lap("chains");
   // 4. unitigs
   const size_t n_nodes = heads.size();
   out.n_nodes = n_nodes;
   out.node_rec.assign(n_nodes * 16, 0);
   out.node_ledge.assign(n_nodes * 4, 0);
   std::vector<uint32_t> kmer_node(n), kmer_off(n);
-  std::vector<uint32_t> tail(n_nodes);
+  std::vector<uint32_t> tail(n_nodes), node_len(n_nodes);
+  parallel_slices(n_nodes, threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t nd = lo; nd < hi; ++nd) {
+      uint32_t o = 0, c = heads[nd], last = c;
+      for (; c != UINT32_MAX; c = next[c]) {
+        kmer_node[c] = (uint32_t)nd;
+        kmer_off[c] = o++;
+        last = c;
+      }
+      tail[nd] = last;
+      node_len[nd] = o;
+    }
+  });
   uint64_t bases = 0;
   for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint32_t o = 0, c = heads[nd], last = c;
-    for (; c != UINT32_MAX; c = next[c]) {
-      kmer_node[c] = (uint32_t)nd;
-      kmer_off[c] = o++;
-      last = c;
-    }
-    tail[nd] = last;
-    uint64_t len = (uint64_t)o + KMER - 1;
+    const uint32_t last = tail[nd];
+    uint64_t len = (uint64_t)node_len[nd] + KMER - 1;
     if (bases + len >= (1ULL << 32)) throw std::runtime_error("index build: unitig buffer exceeds 2^32 bases");
     if (len >= (1u << 24)) throw std::runtime_error("index build: unitig longer than 2^24 bases");
     const uint32_t e = (uint32_t)(exts[heads[nd]] & 0xF) | ((uint32_t)(exts[last] >> 4) << 4);
@@ -160,26 +266,33 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   }
   out.unitig_bases = bases;
   out.unitig.assign((bases + 31) / 32 + 4, 0);  // +4 words so a 3-word window never reads past the end
-  auto put_base = [&](uint64_t pos, uint64_t b) { out.unitig[pos >> 5] |= b << (62 - 2 * (pos & 31)); };
-  for (size_t nd = 0; nd < n_nodes; ++nd) {
-    uint64_t pos = out.node_rec[nd * 16 + 2];
-    uint64_t inl[4] = {0, 0, 0, 0};
-    uint32_t k = 0;
-    auto put = [&](uint64_t b) {
-      put_base(pos++, b);
-      if (k < NODE_INLINE_BASES) inl[k >> 5] |= b << (62 - 2 * (k & 31));
-      ++k;
-    };
-    uint64_t first = kmers[heads[nd]];
-    for (uint32_t b = 0; b < KMER; ++b) put((first >> (2 * (KMER - 1 - b))) & 3);
-    for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put(kmers[c] & 3);
-    for (int w = 0; w < 2; ++w) {
-      out.node_rec[nd * 16 + 12 + 2 * w] = (uint32_t)inl[w];
-      out.node_rec[nd * 16 + 13 + 2 * w] = (uint32_t)(inl[w] >> 32);
+  // neighbouring unitigs share a word of the packed buffer: OR the bases in atomically
+  auto put_base = [&](uint64_t pos, uint64_t b) {
+    if (b) __atomic_fetch_or(&out.unitig[pos >> 5], b << (62 - 2 * (pos & 31)), __ATOMIC_RELAXED);
+  };
+  parallel_slices(n_nodes, threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t nd = lo; nd < hi; ++nd) {
+      uint64_t pos = out.node_rec[nd * 16 + 2];
+      uint64_t inl[4] = {0, 0, 0, 0};
+      uint32_t k = 0;
+      auto put = [&](uint64_t b) {
+        put_base(pos++, b);
+        if (k < NODE_INLINE_BASES) inl[k >> 5] |= b << (62 - 2 * (k & 31));
+        ++k;
+      };
+      uint64_t first = kmers[heads[nd]];
+      for (uint32_t b = 0; b < KMER; ++b) put((first >> (2 * (KMER - 1 - b))) & 3);
+      for (uint32_t c = next[heads[nd]]; c != UINT32_MAX; c = next[c]) put(kmers[c] & 3);
+      for (int w = 0; w < 2; ++w) {
+        out.node_rec[nd * 16 + 12 + 2 * w] = (uint32_t)inl[w];
+        out.node_rec[nd * 16 + 13 + 2 * w] = (uint32_t)(inl[w] >> 32);
+      }
     }
-  }
+  });
+  timer.lap("unitigs");
   // 5. edges
-  for (size_t nd = 0; nd < n_nodes; ++nd) {
+  parallel_slices(n_nodes, threads, [&](unsigned, size_t lo_, size_t hi_) {
+  for (size_t nd = lo_; nd < hi_; ++nd) {
     uint32_t e = out.node_rec[nd * 16 + 0] >> 24;
     uint64_t firstk = kmers[heads[nd]], lastk = kmers[tail[nd]];
     for (uint32_t b = 0; b < 4; ++b) {
@@ -195,6 +308,8 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
       }
     }
   }
+  });
+  timer.lap("edges");
   // 6. dictionary, load factor <= 0.5
   uint64_t slots = 64;
   uint32_t log2_slots = 6;
@@ -210,21 +325,25 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     out.ht[2 * h] = kmers[i];
     out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
   }
+  timer.lap("dictionary");
   // presence filter: 2 bits in each of 7 lines per k-mer, sized for <= ~16 % bit density, i.e. a false
   // positive rate of ~2.5 % per position (the 24 shared bits allow up to 2^24 lines)
   out.bm_lines_log2 = 8;
   while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND * 2.0 > 0.16 * 128.0 * (double)(1ull << out.bm_lines_log2))
     ++out.bm_lines_log2;
   out.bitmap.assign((size_t)4 << out.bm_lines_log2, 0);
-  for (size_t i = 0; i < n; ++i) {
-    const uint32_t bits = round_bits(kmers[i]);
-    const uint32_t b1 = bits & 127u, b2 = (bits >> 7) & 127u;
-    for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
-      const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
-      out.bitmap[line * 4 + (b1 >> 5)] |= 1u << (b1 & 31);
-      out.bitmap[line * 4 + (b2 >> 5)] |= 1u << (b2 & 31);
+  parallel_slices(n, threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      const uint32_t bits = round_bits(kmers[i]);
+      const uint32_t b1 = bits & 127u, b2 = (bits >> 7) & 127u;
+      for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
+        const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
+        __atomic_fetch_or(&out.bitmap[line * 4 + (b1 >> 5)], 1u << (b1 & 31), __ATOMIC_RELAXED);
+        __atomic_fetch_or(&out.bitmap[line * 4 + (b2 >> 5)], 1u << (b2 & 31), __ATOMIC_RELAXED);
+      }
     }
-  }
+  });
+  timer.lap("presence filter");
   // 7. class descriptors
   out.cls_desc.assign(out.n_colours * 4, 0);
   for (size_t c = 0; c < out.n_colours; ++c) {
@@ -236,6 +355,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     const uint32_t c = out.node_rec[nd * 16 + 1];
     for (int k = 0; k < 4; ++k) out.node_rec[nd * 16 + 3 + k] = out.cls_desc[(size_t)c * 4 + k];
   }
+  timer.lap("class descriptors");
 }
 
 }  // namespace nimble
