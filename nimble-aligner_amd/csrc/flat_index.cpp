@@ -335,7 +335,8 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   parallel_slices(n, threads, [&](unsigned, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
       const uint32_t bits = round_bits(kmers[i]);
-      const uint32_t b1 = bits & 127u, b2 = (bits >> 7) & 127u;
+      const uint32_t half = (bits >> 12) & 1u;
+      const uint32_t b1 = (bits & 63u) + 64u * half, b2 = ((bits >> 6) & 63u) + 64u * half;
       for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
         const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
         __atomic_fetch_or(&out.bitmap[line * 4 + (b1 >> 5)], 1u << (b1 & 31), __ATOMIC_RELAXED);

@@ -51,10 +51,11 @@ constexpr uint32_t SCAN_SHARED = 30 - 3 * (SCAN_ROUND - 1);  // 12 bases
 NIMBLE_HD uint64_t round_line(uint64_t shared, uint32_t lines_log2) {
   return (uint64_t)(((uint32_t)shared * 0x85EBCA6Bu) >> (32u - lines_log2));
 }
-// two filter bits per k-mer (Bloom k = 2 inside the 128-bit line): bits [0,7) and [7,14) of the result
+// two filter bits per k-mer, both in one 64-bit half of the 128-bit line (Bloom k = 2 inside the half): bit
+// positions in [0,6) and [6,12) of the result, the half in bit 12 -- the test is two 64-bit shifts of one word
 NIMBLE_HD uint32_t round_bits(uint64_t km) {
   const uint32_t f = (uint32_t)km ^ (uint32_t)(km >> 31);
-  return (f * 0xC2B2AE35u) >> 18;  // 14 bits
+  return (f * 0xC2B2AE35u) >> 19;  // 13 bits
 }
 // the shared bases of k-mer km when it sits in slot j of a round
 NIMBLE_HD uint64_t round_shared_of_kmer(uint64_t km, uint32_t j) {

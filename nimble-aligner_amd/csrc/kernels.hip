@@ -390,13 +390,12 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
       const uint64_t tail =
           extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
       const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
+      const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
 #pragma unroll
       for (int i = 0; i < (int)SCAN_ROUND; ++i) {
         const uint32_t bb = round_bits(km);
-        const uint32_t b1 = bb & 127u, b2 = (bb >> 7) & 127u;
-        const uint32_t w1 = (b1 >> 5) == 0 ? line.x : ((b1 >> 5) == 1 ? line.y : ((b1 >> 5) == 2 ? line.z : line.w));
-        const uint32_t w2 = (b2 >> 5) == 0 ? line.x : ((b2 >> 5) == 1 ? line.y : ((b2 >> 5) == 2 ? line.z : line.w));
-        maybe |= ((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) << i;
+        const uint64_t hw = (bb >> 12) & 1u ? half1 : half0;
+        maybe |= (uint32_t)((hw >> (bb & 63u)) & (hw >> ((bb >> 6) & 63u)) & 1ULL) << i;
         if (i + 1 < (int)SCAN_ROUND) {
           const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
           km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
