@@ -99,8 +99,9 @@ void nimble_ctx_free(nimble_ctx *);
  * fetched on a side stream that waits only for their own call). */
 void *nimble_ctx_stream(nimble_ctx *);
 
-/* Options: NIMBLE_OPT_COUNTERS (default 1) -- collect the work counters of nimble_call_counters inside the
- * align kernel; switch off for timed runs. */
+/* Options: NIMBLE_OPT_COUNTERS (default 0) -- collect the work counters of nimble_call_counters (probes, nodes,
+ * class entries, seeded, prefiltered) inside the align kernel; costs about a third of that kernel's time, so it is
+ * off unless asked for (reads and unique_keys are always available). */
 enum {
   NIMBLE_OPT_COUNTERS = 1,
   /* percent (10..100, default 100) of the resident block slots the persistent align grid takes.  Below 100 every

@@ -137,7 +137,7 @@ struct nimble_ctx {
   hipEvent_t ev[7] = {};
   bool have_events = false;
   bool called = false;
-  int want_counters = 1;
+  int want_counters = 0;
   int align_grid_pct = 100;
   uint32_t dyn_before = 0, dyn_after = 0;
   // arguments of the call in flight (kept so that finish_call can re-enqueue after growing a pool)
@@ -679,7 +679,7 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
     delete c;
     return fail(NIMBLE_E_HIP, "nimble_ctx_create: side stream / pinned buffers");
   }
-  c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 1);
+  c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 0);
   *out = c;
   return NIMBLE_OK;
 }

@@ -359,6 +359,68 @@ __device__ __forceinline__ bool probe_direct(const DevIndex &ix, Lane &ln, uint3
   return false;
 }
 
+// One round of the seed scan at kmer_pos (<= last_kmer_pos): SCAN_ROUND positions at stride 3, answered by ONE
+// 16-byte line of the presence filter selected by the 12 bases all 7 k-mers share; candidates are verified in the
+// dictionary in read order.  Found: kmer_pos / node / off are set.  Not found: kmer_pos moves past the round.
+__device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
+                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off) {
+  // one round: SCAN_ROUND positions at stride 3, answered by ONE 16-byte line of the presence filter,
+  // selected by the 12 bases all 7 k-mers share
+  uint32_t maybe = 0;
+  {
+    const uint32_t span = KMER + 3u * (SCAN_ROUND - 1);            // 48 bases
+    const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;      // bases of the mate from kmer_pos on
+    uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
+    const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
+    const uint64_t tail =
+        extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
+    const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
+    const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
+#pragma unroll
+    for (int i = 0; i < (int)SCAN_ROUND; ++i) {
+      const uint32_t bb = round_bits(km);
+      const uint64_t hw = (bb >> 12) & 1u ? half1 : half0;
+      maybe |= (uint32_t)((hw >> (bb & 63u)) & (hw >> ((bb >> 6) & 63u)) & 1ULL) << i;
+      if (i + 1 < (int)SCAN_ROUND) {
+        const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
+        km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
+      }
+    }
+  }
+  const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
+  const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
+  maybe &= (1u << nvalid) - 1u;
+  uint32_t examined = nvalid;
+  bool found = false;
+  while (maybe) {  // candidates in read order (filter false positives or a real seed); usually none
+    const uint32_t i = (uint32_t)__ffs((int)maybe) - 1u;
+    maybe &= maybe - 1u;
+    const uint32_t p = kmer_pos + 3u * i;
+    const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
+    const uint64_t h = kmer_slot(km, ix.ht_log2);
+    const uint4 sl = ix.ht[h];
+    const uint64_t key = u64of(sl.x, sl.y);
+    uint64_t v = u64of(sl.z, sl.w);
+    bool hit = key == km;
+    if (!hit && key != HT_EMPTY) {
+      v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
+      hit = v != HT_EMPTY;
+    }
+    if (hit) {
+      found = true;
+      examined = i + 1u;
+      kmer_pos = p;
+      off = (uint32_t)v;
+      node = (uint32_t)(v >> 32);
+      maybe = 0;
+    }
+  }
+  ln.probes += examined;  // the reference examines positions one by one up to the first hit
+  if (found) return true;
+  kmer_pos += 3u * SCAN_ROUND;
+  return false;
+}
+
 // seed search with stride 3 from kmer_pos (positions relative to the mate).  The first probe goes alone
 // (it hits for most on-target reads); after a miss PROBE_BATCH independent probes are kept in flight.
 __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
@@ -378,62 +440,8 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
     }
     kmer_pos += 3;
   }
-  while (kmer_pos <= last_kmer_pos) {
-    // one round: SCAN_ROUND positions at stride 3, answered by ONE 16-byte line of the presence filter,
-    // selected by the 12 bases all 7 k-mers share
-    uint32_t maybe = 0;
-    {
-      const uint32_t span = KMER + 3u * (SCAN_ROUND - 1);            // 48 bases
-      const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;      // bases of the mate from kmer_pos on
-      uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
-      const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
-      const uint64_t tail =
-          extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
-      const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
-      const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
-#pragma unroll
-      for (int i = 0; i < (int)SCAN_ROUND; ++i) {
-        const uint32_t bb = round_bits(km);
-        const uint64_t hw = (bb >> 12) & 1u ? half1 : half0;
-        maybe |= (uint32_t)((hw >> (bb & 63u)) & (hw >> ((bb >> 6) & 63u)) & 1ULL) << i;
-        if (i + 1 < (int)SCAN_ROUND) {
-          const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
-          km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
-        }
-      }
-    }
-    const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
-    const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
-    maybe &= (1u << nvalid) - 1u;
-    uint32_t examined = nvalid;
-    bool found = false;
-    while (maybe) {  // candidates in read order (filter false positives or a real seed); usually none
-      const uint32_t i = (uint32_t)__ffs((int)maybe) - 1u;
-      maybe &= maybe - 1u;
-      const uint32_t p = kmer_pos + 3u * i;
-      const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
-      const uint64_t h = kmer_slot(km, ix.ht_log2);
-      const uint4 sl = ix.ht[h];
-      const uint64_t key = u64of(sl.x, sl.y);
-      uint64_t v = u64of(sl.z, sl.w);
-      bool hit = key == km;
-      if (!hit && key != HT_EMPTY) {
-        v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
-        hit = v != HT_EMPTY;
-      }
-      if (hit) {
-        found = true;
-        examined = i + 1u;
-        kmer_pos = p;
-        off = (uint32_t)v;
-        node = (uint32_t)(v >> 32);
-        maybe = 0;
-      }
-    }
-    ln.probes += examined;  // the reference examines positions one by one up to the first hit
-    if (found) return true;
-    kmer_pos += 3u * SCAN_ROUND;
-  }
+  while (kmer_pos <= last_kmer_pos)
+    if (scan_round(ix, ln, base0, kmer_pos, last_kmer_pos, node, off)) return true;
   return false;
 }
 

@@ -71,6 +71,7 @@ class Case:
         assert row_seqs == self.ref.column(self.ref.sequence_idx)
         self.dindex = nim.Index(row_seqs)
         self.ctx = nim.Context(self.dindex)
+        self.ctx.set_counters(True)
 
     def check(self, r1, o1, r2=None, o2=None, cfg=None, fixed_len=0, table=True):
         cfg = cfg or self.cfg
@@ -114,6 +115,19 @@ class Case:
                 if callset:
                     tab[tuple(callset)] = tab.get(tuple(callset), 0) + cnt
             assert sorted([list(k), v] for k, v in tab.items()) == [[f, c] for f, c in res.rows]
+        # the same call without the work counters (the production instantiation of the align kernel): records and
+        # histogram must not move
+        first = [self.ctx.read_records(m) for m in range(2 if paired else 1)]
+        self.ctx.set_counters(False)
+        try:
+            self.ctx.call(params_from(cfg), r1, o1, r2, o2)
+            for m in range(2 if paired else 1):
+                rec = self.ctx.read_records(m)
+                for k in ("reason", "score", "mismatches", "cls", "counted"):
+                    np.testing.assert_array_equal(rec[k], first[m][k], err_msg="production kernel: %s mate %d" % (k, m))
+            assert self.ctx.histogram() == hist
+        finally:
+            self.ctx.set_counters(True)
         return res
 
 
