@@ -127,6 +127,11 @@ def _records_worker(rank, world, port, out_dir):
         rec[:, 5] = torch.randint(-2 ** 62, 2 ** 62, (n,), generator=g, dtype=torch.int64)  # the key hash column
         dest = nd.hash_partition(rec[:, 5], world)
         got = nd.exchange_records(rec, dest, None)
+        # the pre-grouped form the device routing feeds (records already ordered by destination + counts)
+        order = torch.argsort(dest, stable=True)
+        counts = torch.bincount(dest, minlength=world).tolist()
+        got2 = nd.exchange_routed(rec[order].contiguous(), counts, None)
+        assert torch.equal(got, got2)
         torch.save((rec, got), os.path.join(out_dir, "rec%d.pt" % rank))
     finally:
         dist.destroy_process_group()
