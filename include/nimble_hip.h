@@ -211,6 +211,9 @@ int nimble_stream_end(nimble_ctx *);
 /* page-locked host memory for the batches (full-rate asynchronous H2D) */
 int nimble_pinned_alloc(uint64_t bytes, void **out);
 void nimble_pinned_free(void *);
+/* ... or page-lock a buffer the caller already owns (until nimble_pinned_unregister) */
+int nimble_pinned_register(void *p, uint64_t bytes);
+void nimble_pinned_unregister(void *p);
 
 /* Histogram of the call: one entry per distinct (class of R1, class of R2) over the unique read keys
  * that survived the per-read filters (the `score_map` of src/align.rs:496-505, grouped).

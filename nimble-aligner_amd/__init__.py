@@ -89,7 +89,7 @@ HIP_SYMBOLS = [
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
     "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
-    "nimble_route_records", "nimble_unpack_records",
+    "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
 ]
 
 
@@ -132,6 +132,9 @@ def hip_lib():
         L.nimble_pinned_alloc.argtypes = [u64, C.POINTER(vp)]
         L.nimble_pinned_free.argtypes = [vp]
         L.nimble_pinned_free.restype = None
+        L.nimble_pinned_register.argtypes = [vp, u64]
+        L.nimble_pinned_unregister.argtypes = [vp]
+        L.nimble_pinned_unregister.restype = None
         L.nimble_call_ex.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(CallExtra)]
         L.nimble_histogram_seg.argtypes = [vp, vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
         L.nimble_read_align_len.argtypes = [vp, i32, vp, u64]

@@ -1280,6 +1280,20 @@ void nimble_pinned_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
 
+int nimble_pinned_register(void *p, uint64_t bytes) {
+  if (!p || !bytes) return fail(NIMBLE_E_INVALID, "nimble_pinned_register: NULL argument");
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(NIMBLE_E_HIP, std::string("hipHostRegister failed: ") + hipGetErrorString(e));
+  }
+  return NIMBLE_OK;
+}
+
+void nimble_pinned_unregister(void *p) {
+  if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
+
 static int finish_count_stage(nimble_ctx *c) { return finish_call(c); }
 
 int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count, uint64_t cap,

@@ -6,8 +6,13 @@
 // records into batches; the pipeline thread hands batch i to the streamed call of every library
 // (align::CallStream: copy + pack + align of that batch on the GPU) while batch i+1 is being parsed.  It is
 // still ONE score::call per library: dedup and counting run once over everything at the end.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +20,7 @@
 #include <mutex>
 #include <thread>
 
+#include "../../include/nimble_hip.h"
 #include "nimble_host.hpp"
 
 namespace nimble {
@@ -82,6 +88,25 @@ class LineSource {
   bool eof_ = false;
 };
 
+// the same interface over a memory range (a mapped plain file)
+class MemLines {
+ public:
+  MemLines(const uint8_t *d, size_t pos, size_t end) : d_(d), p_(pos), end_(end) {}
+  bool next(const uint8_t *&b, size_t &len) {
+    if (p_ >= end_) return false;
+    b = d_ + p_;
+    const uint8_t *nl = (const uint8_t *)memchr(b, '\n', end_ - p_);
+    len = nl ? (size_t)(nl - b) : end_ - p_;
+    p_ += len + (nl ? 1 : 0);
+    return true;
+  }
+  size_t pos() const { return p_; }
+
+ private:
+  const uint8_t *d_;
+  size_t p_, end_;
+};
+
 inline size_t trimmed(const uint8_t *b, size_t len) {
   while (len > 0 && (b[len - 1] == ' ' || b[len - 1] == '\t' || b[len - 1] == '\r' || b[len - 1] == '\n' ||
                      b[len - 1] == '\f' || b[len - 1] == '\v'))
@@ -92,7 +117,8 @@ inline size_t trimmed(const uint8_t *b, size_t len) {
 // One record of bio::io::fastq::Reader::read appended to `out`: '@' header, sequence lines up to the '+' line,
 // then as many quality lines as there were sequence lines; sequence and quality lengths are not compared.
 // Returns false at a clean EOF; throws on a malformed record.
-bool read_record(LineSource &ln, FastqData &out, const char *malformed) {
+template <class Lines>
+bool read_record(Lines &ln, FastqData &out, const char *malformed) {
   const uint8_t *b;
   size_t len;
   if (!ln.next(b, len)) return false;
@@ -133,8 +159,211 @@ FastqData read_fastq(const std::string &path, bool is_mate) {
   return out;
 }
 
+// Page-lock the batch's buffers for the device copy.  A recycled batch keeps its registration as long as its vectors
+// have not been re-allocated; pinning is best effort (pageable memory still works, only slower).
+void BatchReader::Batch::pin() {
+  static const bool off = getenv("NIMBLE_FASTQ_NO_PIN") != nullptr;
+  if (off) return;
+  void *want[2] = {data.bases.capacity() ? (void *)data.bases.data() : nullptr,
+                   data.offsets.capacity() ? (void *)data.offsets.data() : nullptr};
+  const uint64_t bytes[2] = {data.bases.capacity(), data.offsets.capacity() * sizeof(uint64_t)};
+  for (int k = 0; k < 2; ++k) {
+    if (pinned[k] == want[k]) continue;
+    if (pinned[k]) nimble_pinned_unregister(pinned[k]);
+    pinned[k] = nullptr;
+    if (want[k] && bytes[k] >= (1u << 20) && nimble_pinned_register(want[k], bytes[k]) == 0) pinned[k] = want[k];
+  }
+}
+void BatchReader::Batch::unpin() {
+  for (int k = 0; k < 2; ++k) {
+    if (pinned[k]) nimble_pinned_unregister(pinned[k]);
+    pinned[k] = nullptr;
+  }
+}
+
+// ---- plain (uncompressed) files: chunks of the mapped file are parsed by a pool of threads ------------------
+// Chunk c covers the records that START inside [c * chunk, (c + 1) * chunk).  A worker does not know where the
+// first of them starts, so it guesses (the first line that begins with '@' and whose next-but-one line begins with
+// '+': exact for four-line records) and parses from there; the consumer, who knows where chunk c - 1 really ended,
+// accepts the result when the guess was right and parses the chunk again itself when it was not (multi-line
+// records can fool the guess; the outcome is the same either way, only slower).
+class ParallelPlain {
+ public:
+  typedef BatchReader::Batch Batch;
+  ParallelPlain(const std::string &path, bool is_mate) : is_mate_(is_mate) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw Panic("Error -- could not determine compression format for " + path);
+    struct stat st;
+    if (fstat(fd_, &st) != 0) {
+      close(fd_);
+      throw Panic("Error -- could not determine compression format for " + path);
+    }
+    size_ = (size_t)st.st_size;
+    if (size_) {
+      void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+      if (m == MAP_FAILED) {
+        close(fd_);
+        throw Panic("Error -- could not determine compression format for " + path);
+      }
+      data_ = (const uint8_t *)m;
+      (void)madvise(m, size_, MADV_SEQUENTIAL);
+    }
+    chunk_ = 8u << 20;
+    if (const char *e = getenv("NIMBLE_FASTQ_CHUNK")) chunk_ = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 64);
+    n_chunks_ = size_ ? (size_ + chunk_ - 1) / chunk_ : 1;
+    unsigned t = std::thread::hardware_concurrency();
+    t = t ? std::min(t, 8u) : 4u;
+    if (const char *e = getenv("NIMBLE_FASTQ_THREADS")) t = (unsigned)std::max(1, atoi(e));
+    t = (unsigned)std::min<size_t>(t, n_chunks_);
+    window_ = 2 * (size_t)t + 1;
+    results_.resize(n_chunks_);
+    for (unsigned i = 0; i < t; ++i) workers_.emplace_back([this] { work(); });
+  }
+  ~ParallelPlain() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &w : workers_) w.join();
+    if (data_) munmap((void *)data_, size_);
+    if (fd_ >= 0) close(fd_);
+  }
+  static bool is_plain(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;  // the gzip path reports the failure
+    unsigned char m[2] = {0, 0};
+    size_t got = fread(m, 1, 2, f);
+    fclose(f);
+    return !(got == 2 && m[0] == 0x1f && m[1] == 0x8b);
+  }
+
+  // the next chunk's records, in file order
+  std::unique_ptr<Batch> next() {
+    const size_t c = delivered_;
+    std::unique_ptr<Batch> b;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return results_[c] != nullptr; });
+      b = std::move(results_[c]);
+    }
+    if (b->start != true_start_) {
+      // the guess was wrong (or an earlier chunk ran into this one): parse the chunk from where it really starts
+      parse_range(true_start_, chunk_end(c), *b);
+    }
+    b->pin();
+    true_start_ = b->end;
+    b->raw_offset = b->end;
+    b->last = !b->error.empty() || c + 1 == n_chunks_;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      ++delivered_;
+    }
+    cv_.notify_all();
+    return b;
+  }
+  bool done() const { return delivered_ >= n_chunks_; }
+  void recycle(std::unique_ptr<Batch> b) {
+    std::lock_guard<std::mutex> lk(mu_);
+    pool_.push_back(std::move(b));
+  }
+
+ private:
+  std::unique_ptr<Batch> take() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!pool_.empty()) {
+        std::unique_ptr<Batch> b = std::move(pool_.back());
+        pool_.pop_back();
+        return b;
+      }
+    }
+    std::unique_ptr<Batch> b(new Batch());
+    b->data.bases.reserve(chunk_ / 2 + (chunk_ >> 4));  // one allocation (and one page-lock) per pooled batch
+    b->data.offsets.reserve(chunk_ / 64 + 16);
+    return b;
+  }
+
+  size_t chunk_end(size_t c) const { return std::min(size_, (c + 1) * chunk_); }
+
+  // first record start at or after `from`: a line starting with '@' whose next-but-one line starts with '+'
+  size_t guess_start(size_t from, size_t limit) const {
+    size_t p = from;
+    if (p > 0 && data_[p - 1] != '\n') {
+      const uint8_t *nl = (const uint8_t *)memchr(data_ + p, '\n', size_ - p);
+      if (!nl) return size_;
+      p = (size_t)(nl - data_) + 1;
+    }
+    while (p < limit) {
+      const uint8_t *n1 = (const uint8_t *)memchr(data_ + p, '\n', size_ - p);
+      if (data_[p] == '@' && n1) {
+        const size_t l2 = (size_t)(n1 - data_) + 1;
+        const uint8_t *n2 = l2 < size_ ? (const uint8_t *)memchr(data_ + l2, '\n', size_ - l2) : nullptr;
+        if (n2) {
+          const size_t l3 = (size_t)(n2 - data_) + 1;
+          if (l3 < size_ && data_[l3] == '+') return p;
+        }
+      }
+      if (!n1) return size_;
+      p = (size_t)(n1 - data_) + 1;
+    }
+    return p;  // no record starts inside the chunk
+  }
+
+  // records starting in [start, limit)
+  void parse_range(size_t start, size_t limit, Batch &b) const {
+    b.data.bases.clear();
+    b.data.offsets.assign(1, 0);
+    b.data.max_len = 0;
+    b.error.clear();
+    b.start = start;
+    MemLines ln(data_, start, size_);
+    try {
+      while (ln.pos() < limit && read_record(ln, b.data, malformed_text(is_mate_))) {
+      }
+    } catch (const Panic &e) {
+      b.data.bases.resize(b.data.offsets.back());
+      b.error = e.what();
+    }
+    b.end = std::max(ln.pos(), start);
+  }
+
+  void work() {
+    for (;;) {
+      size_t c;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        // run ahead of the consumer by at most `window_` chunks
+        cv_.wait(lk, [&] { return stop_ || claimed_ >= n_chunks_ || claimed_ < delivered_ + window_; });
+        if (stop_ || claimed_ >= n_chunks_) return;
+        c = claimed_++;
+      }
+      std::unique_ptr<Batch> b = take();
+      const size_t lo = c * chunk_, hi = chunk_end(c);
+      parse_range(c == 0 ? 0 : guess_start(lo, hi), hi, *b);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        results_[c] = std::move(b);
+      }
+      cv_.notify_all();
+    }
+  }
+
+  bool is_mate_;
+  int fd_ = -1;
+  const uint8_t *data_ = nullptr;
+  size_t size_ = 0, chunk_ = 0, n_chunks_ = 0, window_ = 0;
+  std::vector<std::unique_ptr<Batch>> results_, pool_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  size_t claimed_ = 0, delivered_ = 0, true_start_ = 0;
+  bool stop_ = false;
+};
+
 // ---- batch reader: a thread parses ahead, batches are handed over in file order ----------------------
 struct BatchReader::Impl {
+  std::unique_ptr<ParallelPlain> plain;  // plain files: chunk-parallel parse (then no reader thread of our own)
   std::string path;
   bool is_mate;
   size_t batch_reads;
@@ -203,6 +432,11 @@ BatchReader::BatchReader(const std::string &path, bool is_mate, size_t batch_rea
   impl_->path = path;
   impl_->is_mate = is_mate;
   impl_->batch_reads = std::max<size_t>(batch_reads, 1);
+  static const bool serial = getenv("NIMBLE_FASTQ_SERIAL") != nullptr;
+  if (!serial && ParallelPlain::is_plain(path)) {
+    impl_->plain.reset(new ParallelPlain(path, is_mate));
+    return;
+  }
   for (int i = 0; i < 3; ++i) impl_->spare.emplace_back(new Batch());
   impl_->th = std::thread([this] { impl_->run(); });
 }
@@ -217,14 +451,21 @@ BatchReader::~BatchReader() {
 }
 
 std::unique_ptr<BatchReader::Batch> BatchReader::next() {
+  if (impl_->plain) return impl_->plain->next();
   std::unique_lock<std::mutex> lk(impl_->mu);
   impl_->cv.wait(lk, [&] { return !impl_->ready.empty(); });
   std::unique_ptr<Batch> b = std::move(impl_->ready.front());
   impl_->ready.pop_front();
+  lk.unlock();
+  b->pin();
   return b;
 }
 
 void BatchReader::recycle(std::unique_ptr<Batch> b) {
+  if (impl_->plain) {
+    impl_->plain->recycle(std::move(b));
+    return;
+  }
   std::lock_guard<std::mutex> lk(impl_->mu);
   impl_->spare.push_back(std::move(b));
   impl_->cv.notify_all();
@@ -249,6 +490,23 @@ uint64_t file_size(const std::string &p) {
   return s > 0 ? (uint64_t)s : 0;
 }
 
+// One input file as a stream of records: the current batch and how much of it has been consumed.
+struct Cursor {
+  parse::fastq::BatchReader rd;
+  std::unique_ptr<parse::fastq::BatchReader::Batch> b;
+  uint64_t used = 0;
+  Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads) {}
+  uint64_t avail() const { return b ? b->data.n() - used : 0; }
+  bool at_end() const { return b && b->last && used == b->data.n(); }  // the file's event (EOF or bad record) is next
+  void fill() {  // make records available unless the file is at its event
+    while (!b || (used == b->data.n() && !b->last)) {
+      if (b) rd.recycle(std::move(b));
+      b = rd.next();
+      used = 0;
+    }
+  }
+};
+
 // The reference's loop pulls R1 record i, then R2 record i (align.rs:513-541): the first file to hit an event
 // (end of file or a malformed record) at the smaller record index decides how the run ends.
 void streamed(const std::vector<std::string> &input_files,
@@ -256,66 +514,55 @@ void streamed(const std::vector<std::string> &input_files,
               const std::vector<reference_library::Reference> &references,
               const std::vector<align::AlignFilterConfig> &aligner_configs,
               const std::vector<std::string> &output_paths, size_t batch_reads) {
-  using parse::fastq::BatchReader;
   const bool paired = input_files.size() > 1;
-  BatchReader rd1(input_files.at(0), false, batch_reads);
-  std::unique_ptr<BatchReader> rd2;
-  if (paired) rd2.reset(new BatchReader(input_files[1], true, batch_reads));
+  Cursor c1(input_files.at(0), false, batch_reads);
+  std::unique_ptr<Cursor> c2;
+  if (paired) c2.reset(new Cursor(input_files[1], true, batch_reads));
 
   std::vector<std::unique_ptr<align::CallStream>> streams;
   uint32_t stream_max_len = 0;
-  const uint64_t INF = ~0ULL;
   const std::string lengths = "Error -- read and reverse read files do not have matching lengths: ";
   for (;;) {
-    std::unique_ptr<BatchReader::Batch> b1 = rd1.next(), b2;
-    if (paired) b2 = rd2->next();
-    const uint64_t n1 = b1->data.n(), n2 = paired ? b2->data.n() : n1;
-    // record index (inside this batch) at which each file ends or turns malformed; batches that are not the
-    // last one of their file are full, so both batches start at the same record
-    const uint64_t e1 = b1->last ? n1 : INF, e2 = paired && b2->last ? n2 : INF;
-    const uint64_t n = std::min(n1, n2);
+    c1.fill();
+    if (paired) c2->fill();
+    const uint64_t n = paired ? std::min(c1.avail(), c2->avail()) : c1.avail();
     if (streams.empty()) {
-      const uint32_t ml = std::max<uint32_t>(b1->data.max_len, paired ? b2->data.max_len : 0u);
+      const uint32_t ml = std::max<uint32_t>(c1.b->data.max_len, paired ? c2->b->data.max_len : 0u);
       stream_max_len = std::max<uint32_t>(32, (ml + 31u) / 32u * 32u);
       uint64_t cap = n;  // capacity from the bytes the first batch took on disk
-      if (!b1->last && b1->raw_offset > 0 && n1 > 0)
-        cap = (uint64_t)((double)file_size(input_files[0]) / (double)b1->raw_offset * (double)n1 * 1.05) + 1024;
+      if (!c1.b->last && c1.b->raw_offset > 0 && c1.b->data.n() > 0)
+        cap = (uint64_t)((double)file_size(input_files[0]) / (double)c1.b->raw_offset * (double)c1.b->data.n() * 1.05) +
+              1024;
       for (size_t i = 0; i < reference_indices.size(); ++i)
         streams.emplace_back(new align::CallStream(*reference_indices[i], aligner_configs.at(i), paired, stream_max_len,
                                                    std::max<uint64_t>(cap, n)));
     }
-    if (b1->data.max_len > stream_max_len || (paired && b2->data.max_len > stream_max_len)) throw NeedWholeFile();
+    if (c1.b->data.max_len > stream_max_len || (paired && c2->b->data.max_len > stream_max_len)) throw NeedWholeFile();
     if (n) {
+      // offsets are absolute inside each batch's buffer: a slice is the same buffer with a later offsets pointer
       align::ReadBatch a, m;
-      a.bases = b1->data.bases.data();
-      a.offsets = b1->data.offsets.data();
+      a.bases = c1.b->data.bases.data();
+      a.offsets = c1.b->data.offsets.data() + c1.used;
       a.n = n;
-      a.max_len = b1->data.max_len;
+      a.max_len = c1.b->data.max_len;
       if (paired) {
-        m.bases = b2->data.bases.data();
-        m.offsets = b2->data.offsets.data();
+        m.bases = c2->b->data.bases.data();
+        m.offsets = c2->b->data.offsets.data() + c2->used;
         m.n = n;
-        m.max_len = b2->data.max_len;
+        m.max_len = c2->b->data.max_len;
       }
       for (auto &st : streams) st->append(a, paired ? &m : nullptr);
+      c1.used += n;
+      if (paired) c2->used += n;
+      continue;  // look again: one of the files may simply need its next batch
     }
-    if (e1 != INF && e1 <= e2) {  // R1 is pulled first: its end of file ends the run, its bad record panics
-      if (!b1->error.empty()) throw Panic(b1->error);
-      break;
+    // no record pair is available: a file is at its event.  R1 is pulled first, so its event decides a tie.
+    if (c1.at_end()) {
+      if (!c1.b->error.empty()) throw Panic(c1.b->error);
+      break;  // R1 ended: R2's remaining records are never pulled
     }
-    if (e2 != INF) {
-      if (e2 == n1) {
-        // R2's event sits right behind this (full) R1 batch: R1's next record decides whether R2 is pulled at all
-        std::unique_ptr<BatchReader::Batch> nb = rd1.next();
-        if (nb->last && nb->data.n() == 0) {
-          if (!nb->error.empty()) throw Panic(nb->error);
-          break;
-        }
-      }
-      throw Panic(b2->error.empty() ? lengths : b2->error);
-    }
-    rd1.recycle(std::move(b1));
-    if (paired) rd2->recycle(std::move(b2));
+    // R1 still has a record, so R2 is at its event: a missing mate or a malformed one
+    throw Panic(c2->b->error.empty() ? lengths : c2->b->error);
   }
   for (size_t i = 0; i < streams.size(); ++i) {
     align::CallOutput res = streams[i]->finish(references.at(i));

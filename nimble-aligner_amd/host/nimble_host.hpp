@@ -295,8 +295,9 @@ struct FastqData {
 // "... reverse read. Input R2 data malformed." (src/align.rs:541) on a malformed record.
 FastqData read_fastq(const std::string &path, bool is_mate);
 
-// The same reader, incremental: a thread parses ahead and hands over batches of `batch_reads` records in file
-// order.  A malformed record ends the file: the batch before it carries the records that parsed and the
+// The same reader, incremental: batches in file order.  Compressed files: one thread inflates and parses ahead,
+// `batch_reads` records per batch.  Plain files: the mapped file is parsed in 8 MiB chunks by a pool of up to 8 threads
+// (one batch per chunk, whatever it holds).  A malformed record ends the file: the batch before it carries the records that parsed and the
 // reference's panic text in `error` (the consumer decides when that panic fires, as the reference's lazy
 // iterators would).
 class BatchReader {
@@ -306,6 +307,12 @@ class BatchReader {
     bool last = false;        // no further batch follows (end of file, or `error`)
     std::string error;        // panic text of the malformed record that follows data, if any
     uint64_t raw_offset = 0;  // (compressed) file bytes consumed when the batch was closed
+    uint64_t start = 0, end = 0;  // byte range of the records (plain files parsed in parallel chunks)
+    // the two buffers stay page-locked while the batch object is re-used (full-rate asynchronous H2D)
+    void *pinned[2] = {nullptr, nullptr};
+    void pin();
+    void unpin();
+    ~Batch() { unpin(); }
   };
   BatchReader(const std::string &path, bool is_mate, size_t batch_reads);
   ~BatchReader();

@@ -294,7 +294,7 @@ def _fnv_records(records):
     return h
 
 
-def test_batched_fastq_reader_matches_whole_file_reader(tmp_path):
+def test_batched_fastq_reader_matches_whole_file_reader(tmp_path, monkeypatch):
     # the pipeline's threaded reader: same records in the same order for every batch size, plain and gzip,
     # lines that straddle the read window, a malformed record after N good ones
     rng = np.random.default_rng(3)
@@ -309,11 +309,38 @@ def test_batched_fastq_reader_matches_whole_file_reader(tmp_path):
     n, bases, max_len = nim.read_fastq_stats(str(plain))
     assert (n, bases, max_len) == (len(recs), sum(map(len, recs)), max(map(len, recs)))
     want = _fnv_records(recs)
-    for path in (plain, gz):
-        for batch in (1, 7, 1000, 4999, 5000, 5001, 1 << 20):
-            got = nim.read_fastq_batched_stats(str(path), batch)
-            assert got[:3] == (n, bases, max_len) and got[4] == want
-            assert got[3] == len(recs) // batch + 1          # a final (possibly empty) batch closes the file
+    for batch in (1, 7, 1000, 4999, 5000, 5001, 1 << 20):
+        got = nim.read_fastq_batched_stats(str(gz), batch)
+        assert got[:3] == (n, bases, max_len) and got[4] == want
+        assert got[3] == len(recs) // batch + 1          # a final (possibly empty) batch closes the file
+    # plain files are parsed in parallel chunks (one batch per chunk); the chunk size must not matter, nor the
+    # number of threads, and a chunk boundary may fall anywhere (inside a header, a quality line that starts with '@')
+    for chunk, threads in ((64, 3), (100, 1), (997, 8), (4096, 4), (1 << 16, 2), (1 << 30, 4)):
+        monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", str(chunk))
+        monkeypatch.setenv("NIMBLE_FASTQ_THREADS", str(threads))
+        got = nim.read_fastq_batched_stats(str(plain), 1000)
+        assert got[:3] == (n, bases, max_len) and got[4] == want, (chunk, threads)
+    # qualities that begin with '@' or '+', multi-line records: the guessed record starts are often wrong there and
+    # the consumer has to re-parse; the result must still be the sequential reader's
+    tricky = tmp_path / "tricky.fastq"
+    parts, want_recs = [], []
+    for i in range(3000):
+        r = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 120))).astype(np.uint8))
+        q = bytes(rng.choice(list(b"@+I#"), size=len(r)).astype(np.uint8))
+        if i % 5 == 0:   # two sequence lines, two quality lines
+            h = len(r) // 2
+            parts.append(b"@m%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:h], r[h:], q[:h] or b"I", q[h:] or b"I"))
+        else:
+            parts.append(b"@s%d\n%s\n+\n%s\n" % (i, r, q))
+        want_recs.append(r)
+    tricky.write_bytes(b"".join(parts))
+    tn, tb, tm = nim.read_fastq_stats(str(tricky))
+    assert (tn, tb) == (len(want_recs), sum(map(len, want_recs)))
+    for chunk in (64, 333, 5000, 1 << 30):
+        monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", str(chunk))
+        got = nim.read_fastq_batched_stats(str(tricky), 100)
+        assert got[:3] == (tn, tb, tm) and got[4] == _fnv_records(want_recs), chunk
+    monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", "128")
     # a very long line (longer than the 4 MiB window) and CRLF line ends
     big = tmp_path / "big.fastq"
     long_read = b"ACGT" * (3 << 20)
