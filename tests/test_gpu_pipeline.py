@@ -322,14 +322,29 @@ def test_fastq_pipeline_streams_batches(synth_lib, tmp_path, monkeypatch):
     exp = oracle_rows(path, "unstranded", r1, r2)
     want = "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
     lib = nim.Library(path, "unstranded").build_index()
-    for batch in ("777", "1000", "1", "0"):
-        monkeypatch.setenv("NIMBLE_FASTQ_BATCH", batch)
-        if batch == "1" and n > 500:
-            continue  # covered by the reader test; one-read batches over thousands of reads are only slow
-        out = str(tmp_path / ("out_%s.tsv" % batch))
+    # plain files: parallel chunks of any size (the two files are cut at different records and re-paired)
+    for chunk in ("3000", "50000", "1000000000"):
+        monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", chunk)
+        out = str(tmp_path / ("out_c%s.tsv" % chunk))
         nim.fastq_process([f1, f2], [lib], [out])
+        assert open(out).read() == want, chunk
+    monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", "7001")
+    # compressed files: one reader thread per file, fixed batches; "0" = read the whole file first
+    import gzip
+    g1, g2 = str(tmp_path / "r1.fastq.gz"), str(tmp_path / "r2.fastq.gz")
+    for src, dst in ((f1, g1), (f2, g2)):
+        with gzip.open(dst, "wb") as g:
+            g.write(open(src, "rb").read())
+    for batch in ("777", "1000", "0"):
+        monkeypatch.setenv("NIMBLE_FASTQ_BATCH", batch)
+        out = str(tmp_path / ("out_%s.tsv" % batch))
+        nim.fastq_process([g1, g2], [lib], [out])
         assert open(out).read() == want, batch
     monkeypatch.setenv("NIMBLE_FASTQ_BATCH", "777")
+    # a plain R1 with a compressed R2
+    out = str(tmp_path / "out_mixed.tsv")
+    nim.fastq_process([f1, g2], [lib], [out])
+    assert open(out).read() == want
     # two libraries fed from one pass over the files
     lib_b = nim.Library(os.path.join(GOLDEN, "libraries", "basic.json"), "unstranded").build_index()
     o1, o2 = str(tmp_path / "m1.tsv"), str(tmp_path / "m2.tsv")
