@@ -962,6 +962,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
 // kernel boundary so that no lane ever waits on another lane.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
+  if (cb.state[8] == 0) return;  // no class was parked in the scratch pool: nothing is pending (the usual case)
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t n = cb.n;
   const int m = (int)blockIdx.y;
@@ -1004,6 +1005,7 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
 }
 
 __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
+  if (cb.state[8] == 0) return;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int m = (int)blockIdx.y;
   if (i >= cb.n) return;
