@@ -44,7 +44,7 @@ std::string lower(std::string s) {
 int main(int argc, char **argv) {
   std::vector<std::string> refs, outs, ins;
   std::string cores = "1", strand = "unstranded", trim;
-  bool have_trim = false;
+  bool have_trim = false, have_cores = false;
   int device = 0;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
     if (a == "-r" || a == "--reference") multi(refs);
     else if (a == "-o" || a == "--output") multi(outs);
     else if (a == "-i" || a == "--input") multi(ins);
-    else if (a == "-c" || a == "--cores") single(cores);
+    else if (a == "-c" || a == "--cores") { single(cores); have_cores = true; }
     else if (a == "-f" || a == "--strand_filter") single(strand);
     else if (a == "-t" || a == "--trim") { single(trim); have_trim = true; }
     else if (a == "-p" || a == "--force_bam_paired") { /* BAM only */ }
@@ -72,6 +72,12 @@ int main(int argc, char **argv) {
     char *end = nullptr;
     (void)strtoull(cores.c_str(), &end, 10);
     if (!end || *end) throw Panic("Error -- please provide an integer value for the number of cores");
+    // the reference spends its cores on alignment (build_index threads, the BAM consumer pool); here they are the
+    // host threads of the index build and of the FASTQ parser.  Without -c the host picks (up to 8 parser threads).
+    if (have_cores) {
+      setenv("NIMBLE_INDEX_THREADS", cores.c_str(), 0);
+      setenv("NIMBLE_FASTQ_THREADS", cores.c_str(), 0);
+    }
     align::LibraryChemistry chem;
     if (strand == "unstranded") chem = align::LibraryChemistry::Unstranded;
     else if (strand == "fiveprime") chem = align::LibraryChemistry::FivePrime;
