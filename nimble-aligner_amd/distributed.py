@@ -291,7 +291,7 @@ class ShardedPipeline:
         got, kw, max_len, paired = self.arrived
         self.arrived = None
         slot = b % 2
-        shard = self.nim.PackedTensors.unpack(self.util, got, kw, max_len, paired,
+        shard = self.nim.PackedTensors.unpack(self.lib.device_context(slot), got, kw, max_len, paired,
                                               out=self._packed(("shard", b % 3), int(got.shape[0]), max_len, paired))
         self.lib.score_call_packed_begin(slot, shard)
         self.inflight[slot] = shard

@@ -382,7 +382,12 @@ nimble_ctx *PseudoAligner::ctx(int slot) {
   if (slot == 0) return ctx_;
   if (slot != 1 && slot != 2) throw Panic("PseudoAligner::ctx: slot must be 0, 1 or 2");
   nimble_ctx *&c = extra_[slot - 1];
-  if (!c) check_rc(nimble_ctx_create(index_, nimble_ctx_stream(ctx_), &c), "nimble_ctx_create");
+  // slot 1 launches on slot 0's stream (calls in flight stay in order); the utility context gets a stream of its
+  // own when NIMBLE_UTIL_STREAM is set (experiment: pack / route beside the align kernel of the call in flight)
+  static const bool util_own = getenv("NIMBLE_UTIL_STREAM") != nullptr;
+  if (!c)
+    check_rc(nimble_ctx_create(index_, (slot == 2 && util_own) ? nullptr : nimble_ctx_stream(ctx_), &c),
+             "nimble_ctx_create");
   return c;
 }
 
