@@ -122,6 +122,41 @@ for it in range(ITER):
         if rng.random() < 0.5:   # proper mates: reverse complement of the same template
             r2 = [x.decode().upper().replace("N", "A")[::-1].translate(str.maketrans("ACGT", "TGCA")).encode() for x in r1]
         b2, o2 = nim.pack_reads(r2)
+    if rng.random() < 0.3:
+        # the BAM pipeline's form of the call: UMI groups, quality trim, SKIP_ALIGN dummies
+        seg = rng.integers(0, max(1, n // int(rng.integers(1, 20))) + 1, size=n).astype(np.uint32)
+        if rng.random() < 0.5:
+            seg = np.sort(seg)
+        def quals(off):
+            q = rng.integers(0, 90, size=int(off[-1]), dtype=np.uint8)
+            if rng.random() < 0.5:
+                q[:] = 73
+                cut = rng.integers(0, len(q) + 1, size=max(1, len(q) // 200))
+                for c in cut:
+                    q[c:c + 40] = rng.integers(0, 10, size=len(q[c:c + 40]), dtype=np.uint8)
+            return q
+        use_q = rng.random() < 0.7
+        q1 = quals(o1) if use_q else None
+        q2 = quals(o2) if (use_q and paired) else None
+        sk1 = (rng.random(n) < 0.05).astype(np.uint8) if rng.random() < 0.5 else None
+        sk2 = (rng.random(n) < 0.1).astype(np.uint8) if (paired and rng.random() < 0.5) else None
+        expu = ora.call_umi(oidx, ref, cfg, b1, o1, b2, o2, q1=q1, q2=q2, skip1=sk1, skip2=sk2, segment=seg,
+                            keep_per_read=True)
+        rows, _ = lib.score_call_umis(b1, o1, b2, o2, segment=seg, qual=(q1, q2), skip=(sk1, sk2))
+        if [(sg, f, c) for sg, f, c, _ in rows] != [(sg, f, c) for sg, f, c in expu.rows]:
+            raise SystemExit("iteration %d: UMI TABLE MISMATCH\n got %s\n exp %s" % (it, rows[:5], expu.rows[:5]))
+        ctx = lib.device_context()
+        ctx.n = n
+        for m in range(2 if paired else 1):
+            rec = ctx.read_records(m)
+            for k in ("reason", "score", "mismatches"):
+                if not np.array_equal(rec[k], expu.per_read[k][m]):
+                    bad = int(np.nonzero(rec[k] != expu.per_read[k][m])[0][0])
+                    raise SystemExit("iteration %d: UMI %s of mate %d differs at read %d: got %d exp %d" %
+                                     (it, k, m, bad, rec[k][bad], expu.per_read[k][m][bad]))
+        if it % 25 == 0:
+            print("iteration", it, "ok (UMI mode, %d reads, %d rows) %.0fs" % (n, len(rows), time.time() - t0), flush=True)
+        continue
     exp = ora.call(oidx, ref, cfg, b1, o1, b2, o2, keep_per_read=True)
     got = lib.score_call(b1, o1, b2, o2)
     if [(f, c) for f, c in got] != [(f, c) for f, c in exp.rows]:
