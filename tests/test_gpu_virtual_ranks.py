@@ -1,0 +1,156 @@
+"""The multi-GPU pipeline with several VIRTUAL ranks on one GPU: one thread per rank, each with its own library /
+index / contexts, torch.distributed replaced by an in-process stand-in whose collectives meet at barriers.  Uneven
+all-to-all splits, the key agreement of the count reduction and the pipelining over batches run exactly the code the
+real ranks run; only the transport is faked.  The merged table must equal one call over the union of all reads."""
+import importlib
+import threading
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+nim = importlib.import_module("nimble-aligner_amd")
+synth = importlib.import_module("nimble-aligner_amd.synth")
+nd = importlib.import_module("nimble-aligner_amd.distributed")
+
+
+class FakeDist:
+    """The subset of torch.distributed the pipeline uses, for `world` threads of one process."""
+    ReduceOp = types.SimpleNamespace(SUM="sum")
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.tl = threading.local()
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def is_initialized(self):
+        return True
+
+    def _meet(self, value):
+        r = self.tl.rank
+        self.slots[r] = value
+        self.bar.wait()
+        got = list(self.slots)
+        self.bar.wait()
+        return got
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        import torch
+        r = self.tl.rank
+        torch.cuda.current_stream().synchronize()
+        everyone = self._meet((inp, input_split_sizes))
+        pieces = []
+        for t, splits in everyone:
+            if splits is None:
+                per = t.shape[0] // self.world
+                pieces.append(t[r * per:(r + 1) * per])
+            else:
+                off = sum(splits[:r])
+                pieces.append(t[off:off + splits[r]])
+        cat = torch.cat(pieces) if pieces else inp[:0]
+        assert cat.shape[0] == out.shape[0]
+        out.copy_(cat)
+        torch.cuda.current_stream().synchronize()
+        self.bar.wait()   # nobody re-uses its send buffer before everyone has copied
+
+    def all_reduce(self, t, op=None, group=None):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        everyone = self._meet(t.clone())
+        total = everyone[0].clone()
+        for x in everyone[1:]:
+            total += x.to(total.device)
+        t.copy_(total)
+        torch.cuda.current_stream().synchronize()
+
+    def all_gather_object(self, out_list, obj, group=None):
+        everyone = self._meet(obj)
+        out_list[:] = everyone
+
+
+@pytest.mark.parametrize("world,paired", [(2, False), (3, False), (2, True)])
+def test_sharded_pipeline_with_virtual_ranks(world, paired, monkeypatch, tmp_path):
+    torch = pytest.importorskip("torch")
+    names, seqs = synth.make_library(160)
+    path = str(tmp_path / "lib.json")
+    synth.write_library(path, names, seqs)
+    device = torch.device("cuda", 0)
+    n_batches = 5
+    # every rank has its own reads per batch; some reads are copied across ranks and batches of the same step so that
+    # duplicates really have to meet on one rank
+    rng = np.random.default_rng(5)
+    batches = []
+    for b in range(n_batches):
+        per_rank = []
+        for r in range(world):
+            n = 6000 + 500 * r + 300 * b
+            if paired:
+                r1, r2 = synth.make_reads(seqs, n, paired=True, seed=1000 + 10 * b + r)
+            else:
+                r1, r2 = synth.make_reads(seqs, n, seed=1000 + 10 * b + r), None
+            per_rank.append([r1.copy(), None if r2 is None else r2.copy()])
+        for _ in range(400):   # cross-rank duplicates inside the step
+            a, c = rng.integers(0, world, size=2)
+            i, j = rng.integers(0, per_rank[a][0].shape[0]), rng.integers(0, per_rank[c][0].shape[0])
+            per_rank[c][0][j] = per_rank[a][0][i]
+            if paired:
+                per_rank[c][1][j] = per_rank[a][1][i]
+        batches.append(per_rank)
+    # what one GPU says about the union of each step's reads
+    single = nim.Library(path, "unstranded").build_index()
+    want = []
+    for per_rank in batches:
+        u1 = np.concatenate([x[0] for x in per_rank])
+        o = synth.fixed_offsets(u1.shape[0], 150)
+        if paired:
+            u2 = np.concatenate([x[1] for x in per_rank])
+            want.append(single.score_call(u1.reshape(-1), o, u2.reshape(-1), o))
+        else:
+            want.append(single.score_call(u1.reshape(-1), None, n=u1.shape[0], fixed_len=150))
+    assert all(len(w) > 50 for w in want)
+
+    fake = FakeDist(world)
+    monkeypatch.setattr(nd, "dist", fake)
+    results = [None] * world
+    errors = []
+
+    def rank_main(r):
+        try:
+            fake.tl.rank = r
+            torch.cuda.set_device(0)
+            lib = nim.Library(path, "unstranded").build_index()
+            red = nd.TableReducer(device)
+            pipe = nd.ShardedPipeline(lib, device, red)
+            outs = []
+            # first step through the unpipelined form (as bench.py does), the rest through the pipeline
+            d1 = torch.from_numpy(batches[0][r][0]).to(device)
+            d2 = None if not paired else torch.from_numpy(batches[0][r][1]).to(device)
+            torch.cuda.synchronize()
+            outs.append(red.rows(*nd.sharded_step(lib, d1, d2, d1.shape[0], 150, device, red)))
+            for b in range(1, n_batches):
+                d1 = torch.from_numpy(batches[b][r][0]).to(device)
+                d2 = None if not paired else torch.from_numpy(batches[b][r][1]).to(device)
+                torch.cuda.synchronize()
+                got = pipe.submit(d1, d2, d1.shape[0], 150)
+                if got is not None:
+                    outs.append(red.rows(*got))
+            outs += [red.rows(*g) for g in pipe.flush()]
+            results[r] = outs
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((r, repr(e)))
+            fake.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(world):
+        assert results[r] == want, "rank %d" % r
