@@ -38,6 +38,9 @@ def main():
                          "exchange with the previous call)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU step (route, all-to-all, reduce over RCCL) even with one rank")
+    ap.add_argument("--form", choices=("sharded", "local"), default=os.environ.get("NIMBLE_MULTI_GPU_FORM", "sharded"),
+                    help="multi-GPU step: 'sharded' moves the packed reads to the key's owner, 'local' aligns where "
+                         "the reads are and moves only keys and verdict bytes")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
@@ -128,10 +131,10 @@ def main():
             end(s)
     pipe = None
     if sharded and not args.no_pipeline:
-        pipe = nd.ShardedPipeline(lib, device, reducer)
-        for s_ in range(3):
+        pipe = (nd.LocalAlignPipeline if args.form == "local" else nd.ShardedPipeline)(lib, device, reducer)
+        for s_ in range(4 if args.form == "local" else 3):
             lib.device_context(s_).set_counters(False)
-        for _ in range(max(args.warmup, 1)):   # allocates the second call slot and the utility context
+        for _ in range(max(args.warmup, 3)):   # allocates the other call slots and the utility context
             pipe.submit(reads, None, n, L)
         for r in pipe.flush():
             rows = r
@@ -193,8 +196,11 @@ def main():
                         "(%d index rows), basic.json settings (score_percent 0.33, score_threshold 50, "
                         "num_mismatches 0), unstranded" % (n, L, args.features, 2 * args.features),
             "reads_per_gpu": n, "read_len": L, "features": args.features,
-            "parallelism": ("1 process/GPU; packed reads routed by key hash (all-to-all) + count all-reduce (RCCL)"
-                            + ("" if args.no_pipeline else "; exchange of step i overlaps the call of step i-1"))
+            "parallelism": (("1 process/GPU; reads aligned where they are, keys to their owner by hash (all-to-all), "
+                             "verdict bytes back (all-to-all) + count all-reduce (RCCL); key exchange of step i "
+                             "beside its own alignment" if args.form == "local" and not args.no_pipeline else
+                             "1 process/GPU; packed reads routed by key hash (all-to-all) + count all-reduce (RCCL)"
+                             + ("" if args.no_pipeline else "; exchange of step i overlaps the call of step i-1")))
                            if sharded else "single GPU",
             "rows": len(rows) if not sharded else len(reducer.rows(*rows)),
             "calls_in_flight": depth,

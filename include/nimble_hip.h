@@ -188,11 +188,33 @@ int nimble_call_packed(nimble_ctx *, const nimble_align_params *, const nimble_p
  * len0 | len1 << 16 | pre0 << 32 | pre1 << 40].  nimble_route_records groups the n packed reads by destination
  * rank (key hash mod world; order inside a destination is arbitrary) into `records` (device, n * (key_words + 2)
  * u64) and returns the number of records per destination in counts[world] (host) -- the split sizes of the
- * all-to-all; complete on return.  nimble_unpack_records turns received records back into packed arrays on the
+ * all-to-all; complete on return.  With counts == NULL it only enqueues the routing on the context's stream;
+ * nimble_route_counts(ctx, counts) then waits for that routing alone -- work enqueued behind it in the meantime
+ * keeps running -- and returns the counts.  nimble_unpack_records turns received records back into packed arrays on the
  * context's stream (nimble_call_packed on the same context may follow without a wait). */
 int nimble_route_records(nimble_ctx *, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
                          uint64_t *counts);
 int nimble_unpack_records(nimble_ctx *, const uint64_t *records, uint64_t n, const nimble_packed *out);
+
+/* ---- multi-GPU, second form: align where the reads are.  Only the keys travel: the rank that owns a key (hash
+ *      mod world) sees every copy of it and answers one byte per copy -- 1 = this copy stands for the key in
+ *      `score_map` (src/align.rs:496-505,685; any copy may, since the classes follow from the key) -- and the rank
+ *      that aligned the read counts it.  Per-read records and classes never leave the rank that read the input.
+ *
+ *      nimble_ctx_defer_dedup arms the NEXT nimble_call on the context (plain call, single-end or fixed-length
+ *      mates): after packing it routes the keys into `records` (device, n * (key_words + 2) u64, grouped by
+ *      destination as nimble_route_records does) and `perm` (device, n u32: read index -> record slot), then
+ *      aligns, and stops before the dedup.  nimble_route_counts waits for the routing only (the alignment keeps
+ *      running) and returns the split sizes of the all-to-all (counts: host, world entries).  The owner runs nimble_dedup_records over the
+ *      records it received (any context without a call in flight; asynchronous on its stream; verdict = device,
+ *      one byte per record, in record order).  The verdict bytes go back by the inverse all-to-all, and
+ *      nimble_count_verdicts (verdict in this rank's record order; must stay alive until the first getter) closes
+ *      the call: pair filter, count, compaction.  The getters then behave as after nimble_call, the histogram
+ *      holding this rank's share of the counts (sum over ranks = the single-GPU table). */
+int nimble_ctx_defer_dedup(nimble_ctx *, uint32_t world, uint64_t *records, uint32_t *perm);
+int nimble_route_counts(nimble_ctx *, uint64_t *counts);
+int nimble_dedup_records(nimble_ctx *, const uint64_t *records, uint64_t n, uint32_t key_words, uint8_t *verdict);
+int nimble_count_verdicts(nimble_ctx *, const uint8_t *verdict);
 
 /* ---- streamed form of the call: ONE score::call whose reads arrive in batches (a FASTQ file larger than one
  *      buffer; src/process/fastq.rs:15-29 feeds the whole file to a single score::call, so the dedup scope is

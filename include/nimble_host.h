@@ -62,7 +62,7 @@ int nimble_library_build_index(nimble_library *, int device);
 /* the device handles behind the library's PseudoAligner (NULL before build_index); borrowed */
 void *nimble_library_index(nimble_library *);
 void *nimble_library_ctx(nimble_library *);
-void *nimble_library_ctx_slot(nimble_library *, int slot); /* context of slot 0 / 1 (calls) or 2 (utility); NULL on error */
+void *nimble_library_ctx_slot(nimble_library *, int slot); /* context of slot 0 / 1 / 3 (calls) or 2 (utility); NULL on error */
 
 /* score::call.  r2 == NULL for single-end; *_off == NULL means fixed_len; mem as in nimble_hip.h */
 int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
@@ -70,7 +70,7 @@ int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_of
                       nimble_rows **out);
 /* score::call in two halves, for callers that stream batches (the BAM pipeline calls score::call once per UMI
  * batch, src/process/bam.rs:183-226): begin enqueues the device work of one batch and returns; end waits for that
- * slot and returns its sorted rows.  Two slots (0, 1) share one launch stream, so batch i+1 runs on the GPU while
+ * slot and returns its sorted rows.  The call slots (0, 1 and 3) share one launch stream, so batch i+1 runs on the GPU while
  * the host turns batch i's histogram into rows.  The read buffers of a slot are borrowed until its end. */
 int nimble_score_call_begin(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem);

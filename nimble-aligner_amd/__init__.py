@@ -90,6 +90,7 @@ HIP_SYMBOLS = [
     "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
+    "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
 ]
 
 
@@ -140,6 +141,10 @@ def hip_lib():
         L.nimble_read_align_len.argtypes = [vp, i32, vp, u64]
         L.nimble_route_records.argtypes = [vp, C.POINTER(NimblePacked), u64, u32, vp, vp]
         L.nimble_unpack_records.argtypes = [vp, vp, u64, C.POINTER(NimblePacked)]
+        L.nimble_ctx_defer_dedup.argtypes = [vp, u32, vp, vp]
+        L.nimble_route_counts.argtypes = [vp, vp]
+        L.nimble_dedup_records.argtypes = [vp, vp, u64, u32, vp]
+        L.nimble_count_verdicts.argtypes = [vp, vp]
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
         _hip = L
@@ -178,6 +183,11 @@ def _ptr(x):
     if hasattr(x, "data_ptr"):
         return x.data_ptr()
     raise TypeError(type(x))
+
+
+def key_words(max_len, paired):
+    """u64 words of one packed read key (nimble_key_words)."""
+    return int(hip_lib().nimble_key_words(int(max_len), int(bool(paired))))
 
 
 def flat_index_stats(sequences):
@@ -346,6 +356,43 @@ class Context:
 
     def set_option(self, option, value):
         _check(hip_lib().nimble_ctx_set_option(self.h, option, int(value)))
+
+    def stream_ptr(self):
+        """The HIP stream the context launches on (an integer; torch.cuda.ExternalStream wraps it)."""
+        return int(hip_lib().nimble_ctx_stream(self.h) or 0)
+
+    # -- align-where-the-reads-are form of the multi-GPU step (include/nimble_hip.h) --
+    def defer_dedup(self, world, records, perm):
+        """Arm the next call: route its keys into `records` [n, key_words + 2] int64 / `perm` [n] int32 (device
+        tensors) and stop before the dedup; world = 0 disarms."""
+        if not world:
+            _check(hip_lib().nimble_ctx_defer_dedup(self.h, 0, None, None))
+            return
+        assert records.is_contiguous() and perm.is_contiguous() and perm.element_size() == 4
+        self._defer_keep = (records, perm)
+        _check(hip_lib().nimble_ctx_defer_dedup(self.h, world, C.c_void_p(records.data_ptr()),
+                                                C.c_void_p(perm.data_ptr())))
+
+    def route_counts(self, world):
+        """Records per destination rank of the last routing on this context (a deferred call's, or route(wait=False));
+        waits for that routing only."""
+        counts = np.zeros(256, dtype=np.uint64)
+        _check(hip_lib().nimble_route_counts(self.h, counts.ctypes.data))
+        return [int(c) for c in counts[:world]]
+
+    def dedup_records(self, records, key_words, verdict):
+        """Owner side: verdict[j] = 1 for one copy of every key among `records` (device tensors; asynchronous)."""
+        n = int(records.shape[0])
+        assert records.is_contiguous() and verdict.is_contiguous() and verdict.numel() >= n
+        assert n == 0 or records.shape[1] == key_words + 2
+        self._dedup_keep = (records, verdict)
+        _check(hip_lib().nimble_dedup_records(self.h, C.c_void_p(records.data_ptr()), n, key_words,
+                                              C.c_void_p(verdict.data_ptr())))
+
+    def count_verdicts(self, verdict):
+        """Close the deferred call with the owners' verdicts (uint8 device tensor in this rank's record order)."""
+        self._verdict_keep = verdict
+        _check(hip_lib().nimble_count_verdicts(self.h, C.c_void_p(verdict.data_ptr())))
 
     def set_counters(self, on):
         _check(hip_lib().nimble_ctx_set_option(self.h, 1, int(bool(on))))
@@ -581,16 +628,20 @@ class PackedTensors:
                 | (self.pre1.to(torch.int64) << 40))
         return torch.cat([self.keys.t(), self.hash[:, None], meta[:, None]], dim=1).contiguous()
 
-    def route(self, ctx, world, out=None):
+    def route(self, ctx, world, out=None, wait=True):
         """Group the reads by destination rank (key hash mod world) into exchange records with the device kernels
         (nimble_route_records).  Returns (records [n, key_words + 2] int64 on the device, counts per rank list).
-        out: a records tensor of that shape to fill (re-used buffers keep the allocator out of the pipeline)."""
+        out: a records tensor of that shape to fill (re-used buffers keep the allocator out of the pipeline).
+        wait=False only enqueues (counts = None); ctx.route_counts(world) waits for the routing and returns them."""
         import torch
         rec = out if out is not None else torch.empty((max(self.n, 1), self.key_words + 2), dtype=torch.int64,
                                                       device=self.keys.device)[:self.n]
         assert tuple(rec.shape) == (self.n, self.key_words + 2) and rec.is_contiguous()
         counts = np.zeros(world, dtype=np.uint64)
         st = self.as_struct()
+        if not wait:
+            _check(hip_lib().nimble_route_records(ctx.h, C.byref(st), self.n, world, rec.data_ptr(), None))
+            return rec, None
         _check(hip_lib().nimble_route_records(ctx.h, C.byref(st), self.n, world, rec.data_ptr(), counts.ctypes.data))
         return rec, [int(c) for c in counts]
 

@@ -128,6 +128,20 @@ struct nimble_ctx {
   DevBuf b_out_c1, b_out_c2, b_out_cnt, b_out_seg, b_out_rep;
   // BAM-mode extras (nimble_call_ex)
   DevBuf b_route;  // scratch of nimble_route_records
+  // align-where-the-reads-are form (nimble_ctx_defer_dedup): the next call routes its keys and stops before dedup
+  struct Defer {
+    uint32_t world = 0;            // 0 = not armed
+    uint32_t world_of_call = 0;
+    uint32_t counts_world = 0;     // destinations of the last routing (nimble_route_counts)
+    uint64_t *records = nullptr;   // caller's device buffers
+    uint32_t *perm = nullptr;
+    const uint8_t *verdict = nullptr;
+    bool active = false;           // the call in flight is a deferred one
+    bool routed = false;           // its keys were routed (never again: the verdicts follow that record order)
+    bool counted = false;          // nimble_count_verdicts was enqueued
+    hipEvent_t ev_route = nullptr;
+    uint64_t *p_counts = nullptr;  // pinned, 256 entries
+  } defer;
   DevBuf b_seg, b_alen[2], b_skip[2], b_qual[2], b_trim_ls, b_trim_qp, b_hist_rep;
   double trim_strictness = -1.0;
   uint64_t trim_target = ~0ULL;
@@ -176,6 +190,8 @@ struct nimble_ctx {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     if (p_state) (void)hipHostFree(p_state);
     if (p_dyn) (void)hipHostFree(p_dyn);
+    if (defer.ev_route) (void)hipEventDestroy(defer.ev_route);
+    if (defer.p_counts) (void)hipHostFree(defer.p_counts);
   }
 };
 
@@ -299,13 +315,42 @@ int enqueue_compact(nimble_ctx *c) {
   return NIMBLE_OK;
 }
 
+// count stage of a deferred call: the owners' verdicts pick the copies that enter the histogram
+int enqueue_count_verdicts(nimble_ctx *c) {
+  hipStream_t s = c->stream;
+  launch_count_verdicts(s, c->prm, c->cb, c->defer.perm, c->defer.verdict);
+  HIPCHK(hipEventRecord(c->ev[4], s));
+  HIPCHK(hipEventRecord(c->ev[5], s));
+  c->counted_marked = true;
+  int rc = enqueue_compact(c);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return mark_done(c);
+}
+
+// routing of a deferred call's keys, between pack and align: the host waits for ev_route only
+int enqueue_route(nimble_ctx *c) {
+  const uint32_t world = c->defer.world_of_call;
+  const uint64_t cells = (uint64_t)route_grid() * world;
+  uint64_t *block_first = c->b_route.as<uint64_t>();
+  uint64_t *totals = block_first + cells;
+  uint32_t *block_counts = reinterpret_cast<uint32_t *>(totals + 256);
+  launch_route(c->stream, c->cb, world, block_counts, block_first, totals, c->defer.records, c->defer.perm);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->defer.p_counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(c->defer.ev_route, c->stream));
+  c->defer.counts_world = world;
+  c->defer.routed = true;
+  return NIMBLE_OK;
+}
+
 // Head of a call: clear the per-call tables and counters.
 int enqueue_head(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
   HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
-  c->dedup_clean_slots = 0;
+  c->dedup_clean_slots = c->defer.active ? c->dslots : 0;  // a deferred call never touches its own table
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
   if (cb.hist_rep) HIPCHK(hipMemsetAsync(cb.hist_rep, 0, c->hist_slots * 4, s));
@@ -323,6 +368,12 @@ int enqueue_tail(nimble_ctx *c) {
   launch_intern_claim(s, c->ix->dev, cb, 0);
   launch_intern_verify(s, c->ix->dev, cb);
   HIPCHK(hipEventRecord(c->ev[3], s));
+  if (c->defer.active) {
+    // the dedup verdicts come from the keys' owners: the call stays open until nimble_count_verdicts
+    // (a re-enqueue after pool growth already has them)
+    HIPCHK(hipGetLastError());
+    return c->defer.counted ? enqueue_count_verdicts(c) : mark_done(c);
+  }
   launch_dedup(s, c->prm, cb);
   HIPCHK(hipEventRecord(c->ev[4], s));
   if (!cb.fuse_count) launch_count(s, cb);
@@ -344,6 +395,10 @@ int enqueue_call(nimble_ctx *c) {
     launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
                 c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
   HIPCHK(hipEventRecord(c->ev[1], s));
+  if (c->defer.active && !c->defer.routed) {
+    rc = enqueue_route(c);
+    if (rc) return rc;
+  }
   launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct);
   return enqueue_tail(c);
 }
@@ -356,6 +411,7 @@ int redo_dedup_count(nimble_ctx *c) {
   if (c->cb.hist_rep) HIPCHK(hipMemsetAsync(c->cb.hist_rep, 0, c->hist_slots * 4, s));
   HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 10, 0, 8, s));
   HIPCHK(hipEventRecord(c->ev[3], s));
+  if (c->defer.active) return enqueue_count_verdicts(c);
   launch_dedup(s, c->prm, c->cb);
   HIPCHK(hipEventRecord(c->ev[4], s));
   if (!c->cb.fuse_count) launch_count(s, c->cb);
@@ -369,6 +425,8 @@ int redo_dedup_count(nimble_ctx *c) {
 // collisions, histogram growth).  Idempotent; every getter goes through here.
 int finish_call(nimble_ctx *c) {
   if (c->finished) return NIMBLE_OK;
+  if (c->defer.active && !c->defer.counted)
+    return fail(NIMBLE_E_INVALID, "the call defers its dedup: nimble_count_verdicts has not been called yet");
   for (;;) {
     int rc = fetch_state(c);
     if (rc) return rc;
@@ -874,6 +932,19 @@ static int start_call(nimble_ctx *c) {
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->finished = false;
   c->attempt = 0;
+  c->defer.active = c->defer.world != 0;
+  c->defer.routed = c->defer.counted = false;
+  c->defer.verdict = nullptr;
+  if (c->defer.active) {
+    if (c->streaming || c->cb.seg || !c->cb.fuse_count) {
+      c->defer.active = false;
+      c->defer.world = 0;
+      return fail(NIMBLE_E_INVALID, "deferred dedup needs a plain call whose classes follow from the key "
+                                    "(single-end or fixed-length mates)");
+    }
+    c->defer.world_of_call = c->defer.world;
+    c->defer.world = 0;  // one call per arming
+  }
   int rc = enqueue_call(c);
   if (rc) return rc;
   c->called = true;
@@ -1011,9 +1082,10 @@ static void packed_view(CallBuffers &v, const nimble_packed *pk, uint64_t n) {
   }
 }
 
+int nimble_route_counts(nimble_ctx *c, uint64_t *counts);
 int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
                          uint64_t *counts) {
-  if (!c || !in || !counts || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_route_records: NULL argument");
+  if (!c || !in || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_route_records: NULL argument");
   if (world == 0 || world > 256) return fail(NIMBLE_E_INVALID, "nimble_route_records: world must be 1..256");
   if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0] || (in->paired && (!in->len[1] || !in->pre[1]))))
     return fail(NIMBLE_E_INVALID, "nimble_route_records: packed arrays missing");
@@ -1030,9 +1102,14 @@ int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uin
   packed_view(v, in, n);
   launch_route(c->stream, v, world, block_counts, block_first, totals, records);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));  // counts are on the host and the records complete on return
-  return NIMBLE_OK;
+  if (!c->defer.ev_route) HIPCHK(hipEventCreateWithFlags(&c->defer.ev_route, hipEventDisableTiming));
+  if (!c->defer.p_counts)
+    HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 256 * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipMemcpyAsync(c->defer.p_counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(c->defer.ev_route, c->stream));
+  c->defer.counts_world = world;
+  // counts == NULL: asynchronous; nimble_route_counts waits for exactly this routing and hands the counts over
+  return counts ? nimble_route_counts(c, counts) : NIMBLE_OK;
 }
 
 int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, const nimble_packed *out) {
@@ -1045,6 +1122,65 @@ int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, co
   launch_records_unpack(c->stream, records, v);
   HIPCHK(hipGetLastError());
   return NIMBLE_OK;
+}
+
+// ---- align-where-the-reads-are form of the multi-GPU step -----------------------------------------------------
+int nimble_ctx_defer_dedup(nimble_ctx *c, uint32_t world, uint64_t *records, uint32_t *perm) {
+  if (!c) return fail(NIMBLE_E_INVALID, "nimble_ctx_defer_dedup: NULL context");
+  if (world == 0) {
+    c->defer.world = 0;
+    return NIMBLE_OK;
+  }
+  if (world > 256) return fail(NIMBLE_E_INVALID, "nimble_ctx_defer_dedup: world must be 1..256");
+  if (!records || !perm) return fail(NIMBLE_E_INVALID, "nimble_ctx_defer_dedup: NULL buffer");
+  HIPCHK(hipSetDevice(c->ix->device));
+  const uint64_t cells = (uint64_t)route_grid() * world;
+  int rc = c->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &c->bytes);
+  if (rc) return rc;
+  if (!c->defer.ev_route) HIPCHK(hipEventCreateWithFlags(&c->defer.ev_route, hipEventDisableTiming));
+  if (!c->defer.p_counts) HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 256 * sizeof(uint64_t), hipHostMallocDefault));
+  c->defer.world = world;
+  c->defer.records = records;
+  c->defer.perm = perm;
+  return NIMBLE_OK;
+}
+
+int nimble_route_counts(nimble_ctx *c, uint64_t *counts) {
+  if (!c || !counts) return fail(NIMBLE_E_INVALID, "nimble_route_counts: NULL argument");
+  if (c->defer.counts_world == 0) return fail(NIMBLE_E_INVALID, "nimble_route_counts: nothing was routed");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipEventSynchronize(c->defer.ev_route));  // the routing only; whatever was enqueued behind it keeps running
+  std::copy(c->defer.p_counts, c->defer.p_counts + c->defer.counts_world, counts);
+  return NIMBLE_OK;
+}
+
+int nimble_dedup_records(nimble_ctx *c, const uint64_t *records, uint64_t n, uint32_t key_words, uint8_t *verdict) {
+  if (!c || (n && (!records || !verdict))) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: NULL argument");
+  if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: more than 2^32 records");
+  if (key_words == 0) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: key_words is 0");
+  if (c->called && !c->finished)
+    return fail(NIMBLE_E_INVALID, "nimble_dedup_records: the context holds a call in flight (use another context)");
+  HIPCHK(hipSetDevice(c->ix->device));
+  const uint64_t slots = std::max<uint64_t>(n + n / 2, 1024);
+  int rc = c->b_dedup.ensure(slots * 8, &c->bytes);
+  if (rc) return rc;
+  c->dedup_clean_slots = 0;
+  HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, slots * 8, c->stream));
+  launch_dedup_records(c->stream, records, n, key_words, c->b_dedup.as<uint64_t>(), (uint32_t)slots, verdict);
+  HIPCHK(hipGetLastError());
+  return NIMBLE_OK;
+}
+
+int nimble_count_verdicts(nimble_ctx *c, const uint8_t *verdict) {
+  if (!c) return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: NULL context");
+  if (!c->defer.active || c->finished)
+    return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: no call with deferred dedup in flight");
+  if (c->defer.counted) return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: already called for this call");
+  if (c->cb.n && !verdict) return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: NULL verdicts");
+  HIPCHK(hipSetDevice(c->ix->device));
+  c->defer.verdict = verdict;
+  c->defer.counted = true;
+  return enqueue_count_verdicts(c);
 }
 
 int nimble_call_packed(nimble_ctx *c, const nimble_align_params *p, const nimble_packed *in, uint64_t n,
@@ -1157,6 +1293,8 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   c->stage_busy[0] = c->stage_busy[1] = false;
   c->stage_k = 0;
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  c->defer.active = false;
+  c->defer.world = 0;
   rc = enqueue_head(c);
   if (rc) return rc;
   c->streaming = true;

@@ -101,7 +101,13 @@ void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts,
 // multi-GPU exchange: route packed reads by key hash into fixed-width records, and back into the packed arrays
 uint32_t route_grid();  // blocks of the routing kernels (sizes block_counts / block_first: grid * world entries)
 void launch_route(hipStream_t s, const CallBuffers &cb, uint32_t world, uint32_t *block_counts, uint64_t *block_first,
-                  uint64_t *totals, uint64_t *rec);
+                  uint64_t *totals, uint64_t *rec, uint32_t *perm = nullptr);
+// align-where-the-reads-are form of the multi-GPU step: the key's owner picks one copy per key (verdict bytes in
+// record order); the aligning rank counts the picked copies (perm = read index -> record slot, from launch_route)
+void launch_dedup_records(hipStream_t s, const uint64_t *rec, uint64_t n, uint32_t key_words, uint64_t *table,
+                          uint32_t slots, uint8_t *verdict);
+void launch_count_verdicts(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, const uint32_t *perm,
+                           const uint8_t *verdict);
 void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb);
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
 

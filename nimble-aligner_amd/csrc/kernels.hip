@@ -1249,7 +1249,7 @@ __global__ void k_route_scan(const uint32_t *__restrict__ block_counts, uint32_t
 }
 
 __global__ void k_route_scatter(CallBuffers cb, uint32_t world, const uint64_t *__restrict__ block_first,
-                                uint64_t *__restrict__ rec) {
+                                uint64_t *__restrict__ rec, uint32_t *__restrict__ perm) {
   __shared__ unsigned long long s_cur[256];
   if (threadIdx.x < world) s_cur[threadIdx.x] = block_first[(uint64_t)blockIdx.x * world + threadIdx.x];
   __syncthreads();
@@ -1276,7 +1276,75 @@ __global__ void k_route_scatter(CallBuffers cb, uint32_t world, const uint64_t *
       o[kw] = h;
       o[kw + 1] = (uint64_t)cb.len[0][i] | ((uint64_t)(cb.paired ? cb.len[1][i] : 0u) << 16) |
                   ((uint64_t)cb.pre[0][i] << 32) | ((uint64_t)(cb.paired ? cb.pre[1][i] : 0u) << 40);
+      if (perm) perm[i] = (uint32_t)slot;
     }
+  }
+}
+
+// The same scatter with the records of a wave gathered in LDS first, ordered by destination: every (wave,
+// destination) run is contiguous in LDS and in `rec`, so the write-out goes in runs of whole records instead of one
+// 8-byte word per lane per instruction into 64 different records.  Wave-synchronous: no block barrier in the loop.
+__global__ __launch_bounds__(256) void k_route_scatter_lds(CallBuffers cb, uint32_t world,
+                                                           const uint64_t *__restrict__ block_first,
+                                                           uint64_t *__restrict__ rec, uint32_t *__restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_words[];  // [4 waves][64 records][rw]
+  __shared__ unsigned long long s_cur[256];
+  __shared__ uint32_t s_slot[256];  // [4 waves][64]: global slot of the record at each local position
+  if (threadIdx.x < world) s_cur[threadIdx.x] = block_first[(uint64_t)blockIdx.x * world + threadIdx.x];
+  __syncthreads();
+  const uint32_t kw = cb.key_words, rw = kw + 2;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint64_t *sw = s_words + (size_t)wave * 64u * rw;
+  uint32_t *ss = s_slot + wave * 64u;
+  const uint32_t q64 = 64u / rw, r64 = 64u % rw;
+  for (uint64_t tile = blockIdx.x; tile * 256 < cb.n; tile += gridDim.x) {
+    const uint64_t i = tile * 256 + threadIdx.x;
+    const bool live = i < cb.n;
+    const uint64_t h = live ? cb.key_hash[i] : 0;
+    const uint32_t d = live ? route_of(h, world) : 0xFFFFFFFFu;
+    uint32_t pos = 0, before = 0, n_live = 0;
+    uint64_t slot = 0;
+    for (uint32_t t = 0; t < world; ++t) {
+      const uint64_t m = __ballot(d == t);
+      if (m == 0) continue;
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&s_cur[t], (unsigned long long)cnt);
+      base = __shfl(base, (int)leader, 64);
+      if (d == t) {
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        pos = before + rank;
+        slot = base + rank;
+      }
+      before += cnt;
+    }
+    n_live = before;
+    if (live) {
+      uint64_t *o = sw + (size_t)pos * rw;
+      for (uint32_t w = 0; w < kw; ++w) o[w] = cb.keys[(uint64_t)w * cb.key_stride + i];
+      o[kw] = h;
+      o[kw + 1] = (uint64_t)cb.len[0][i] | ((uint64_t)(cb.paired ? cb.len[1][i] : 0u) << 16) |
+                  ((uint64_t)cb.pre[0][i] << 32) | ((uint64_t)(cb.paired ? cb.pre[1][i] : 0u) << 40);
+      ss[pos] = (uint32_t)slot;
+      if (perm) perm[i] = (uint32_t)slot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes have landed
+    // write-out: linear index x over the wave's n_live * rw words; (p, w) = (x / rw, x % rw) kept incrementally
+    uint32_t pp = lane / rw, ww = lane % rw;
+    const uint32_t total = n_live * rw;
+    for (uint32_t x = lane; x < total; x += 64u) {
+      rec[(uint64_t)ss[pp] * rw + ww] = sw[x];
+      pp += q64;
+      ww += r64;
+      if (ww >= rw) {
+        ww -= rw;
+        ++pp;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the LDS reads are done before the next tile overwrites the staging
   }
 }
 
@@ -1294,6 +1362,80 @@ __global__ void k_records_unpack(const uint64_t *__restrict__ rec, CallBuffers c
     cb.len[1][i] = (uint32_t)((meta >> 16) & 0xFFFF);
     cb.pre[1][i] = (uint8_t)((meta >> 40) & 0xFF);
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU, align-where-the-reads-are form.  The owner of a key (hash mod world) sees every copy of it as an
+// exchange record and answers one byte per record: 1 = this copy stands for the key.  The classes stay on the
+// rank that aligned the read; k_count_verdicts adds the chosen copies to that rank's histogram.
+// ---------------------------------------------------------------------------------------------
+template <bool STAGED>
+__global__ void k_dedup_records(const uint64_t *__restrict__ rec, uint64_t n, uint32_t kw, uint64_t *table,
+                                uint32_t slots, uint8_t *__restrict__ verdict) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];
+  const uint32_t rw = kw + 2;
+  const uint64_t first_rec = (uint64_t)blockIdx.x * blockDim.x;
+  const uint64_t j = first_rec + threadIdx.x;
+  const uint64_t *o = rec + j * rw;
+  if (STAGED) {
+    // the block's records are one contiguous run: load it with full lines, then every lane reads its own row from LDS
+    const uint64_t live = n - first_rec < blockDim.x ? n - first_rec : blockDim.x;
+    const uint64_t *src = rec + first_rec * rw;
+    for (uint64_t w = threadIdx.x; w < live * rw; w += blockDim.x) s_rec[w] = src[w];
+    __syncthreads();
+    o = s_rec + (uint64_t)threadIdx.x * rw;
+  }
+  if (j >= n) return;
+  const uint64_t h = o[kw];
+  const uint64_t meta = o[kw + 1];
+  const uint32_t total = (uint32_t)(meta & 0xFFFF) + (uint32_t)((meta >> 16) & 0xFFFF);
+  const uint32_t nw = (total + 31u) >> 5;
+  const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+  const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)j;
+  uint32_t pos = __umulhi((uint32_t)h, slots);
+  uint8_t first = 0;
+  for (;;) {
+    const uint64_t cur = atomicCAS((unsigned long long *)&table[pos], 0ULL, (unsigned long long)mine);
+    if (cur == 0) {
+      first = 1;
+      break;
+    }
+    if ((uint32_t)(cur >> 32) == tag) {
+      const uint64_t *q = rec + (uint64_t)(uint32_t)cur * rw;
+      const uint64_t m2 = q[kw + 1];
+      bool same = ((uint32_t)(m2 & 0xFFFF) + (uint32_t)((m2 >> 16) & 0xFFFF)) == total;
+      for (uint32_t w = 0; same && w < nw; ++w) same = q[w] == o[w];
+      if (same) break;
+    }
+    pos = pos + 1 == slots ? 0u : pos + 1;
+  }
+  verdict[j] = first;
+}
+
+// The verdict of read i sits at its record slot perm[i] (the order k_route_scatter put the records in).  Same pair
+// filter as k_dedup; classes are a function of the key here (single-end or fixed-length mates), so whichever copy
+// the owner picked may stand for the key.
+__global__ void k_count_verdicts(nimble_align_params p, CallBuffers cb, const uint32_t *__restrict__ perm,
+                                 const uint8_t *__restrict__ verdict) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cb.n) return;
+  const uint32_t c1 = cb.cls[0][i];
+  const uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
+  uint8_t counted = 0;
+  bool live = true;
+  if (cb.paired && p.require_valid_pair) {
+    if (!(c1 != CLS_NONE && c2 != CLS_NONE && c1 == c2)) {
+      cb.reason[0][i] = NIMBLE_R_NOT_MATCHING_PAIR;
+      cb.reason[1][i] = NIMBLE_R_NOT_MATCHING_PAIR;
+      live = false;
+    }
+  }
+  if (live && !(c1 == CLS_NONE && c2 == CLS_NONE) && verdict[perm[i]]) {
+    counted = 1;
+    hist_add(cb, 0u, c1, c2, (uint32_t)i);
+  }
+  cb.counted[i] = counted;
 }
 
 __global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n) {
@@ -1398,10 +1540,31 @@ void launch_hist_dense_se(hipStream_t s, const CallBuffers &cb, int64_t *counts,
 }
 uint32_t route_grid() { return ROUTE_GRID; }
 void launch_route(hipStream_t s, const CallBuffers &cb, uint32_t world, uint32_t *block_counts, uint64_t *block_first,
-                  uint64_t *totals, uint64_t *rec) {
+                  uint64_t *totals, uint64_t *rec, uint32_t *perm) {
   hipLaunchKernelGGL(k_route_count, dim3(ROUTE_GRID), dim3(256), 0, s, cb.key_hash, cb.n, world, block_counts);
   hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(256), 0, s, block_counts, ROUTE_GRID, world, totals, block_first);
-  if (cb.n) hipLaunchKernelGGL(k_route_scatter, dim3(ROUTE_GRID), dim3(256), 0, s, cb, world, block_first, rec);
+  if (cb.n == 0) return;
+  const size_t lds = (size_t)256 * (cb.key_words + 2) * 8;
+  if (lds <= 56 * 1024)
+    hipLaunchKernelGGL(k_route_scatter_lds, dim3(ROUTE_GRID), dim3(256), lds, s, cb, world, block_first, rec, perm);
+  else
+    hipLaunchKernelGGL(k_route_scatter, dim3(ROUTE_GRID), dim3(256), 0, s, cb, world, block_first, rec, perm);
+}
+void launch_dedup_records(hipStream_t s, const uint64_t *rec, uint64_t n, uint32_t key_words, uint64_t *table,
+                          uint32_t slots, uint8_t *verdict) {
+  if (n == 0) return;
+  const size_t lds = (size_t)256 * (key_words + 2) * 8;
+  if (lds <= 48 * 1024)
+    hipLaunchKernelGGL(k_dedup_records<true>, dim3(blocks_for(n, 256)), dim3(256), lds, s, rec, n, key_words, table,
+                       slots, verdict);
+  else
+    hipLaunchKernelGGL(k_dedup_records<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, rec, n, key_words, table,
+                       slots, verdict);
+}
+void launch_count_verdicts(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, const uint32_t *perm,
+                           const uint8_t *verdict) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_count_verdicts, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, p, cb, perm, verdict);
 }
 void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb) {
   if (cb.n == 0) return;

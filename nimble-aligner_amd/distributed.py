@@ -150,9 +150,10 @@ def reduce_tables(rows, device, group=None):
     return [(k.split("\t"), int(counts[i])) for i, k in enumerate(universe) if counts[i]]
 
 
-def exchange_routed(rec, counts, group=None, alloc=None, staging=None):
+def exchange_routed(rec, counts, group=None, alloc=None, staging=None, with_counts=False):
     """all_to_all of records already grouped by destination rank (`counts` records per rank).  alloc(rows) may
-    supply the receive buffer; staging (a _Staging) keeps the small host <-> device copies page-locked."""
+    supply the receive buffer; staging (a _Staging) keeps the small host <-> device copies page-locked.
+    with_counts: also return the number of records received from each rank."""
     st = staging or _Staging(rec.device)
     send_counts = st.to_device("send_counts", counts)
     recv = torch.empty_like(send_counts)
@@ -161,7 +162,7 @@ def exchange_routed(rec, counts, group=None, alloc=None, staging=None):
     rows = sum(out_split)
     got = alloc(rows) if alloc else torch.empty((rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_to_all_single(got, rec, output_split_sizes=out_split, input_split_sizes=list(counts), group=group)
-    return got
+    return (got, out_split) if with_counts else got
 
 
 class TableReducer:
@@ -313,11 +314,11 @@ class ShardedPipeline:
         pt = self.lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=self.nim.MEM_DEVICE,
                            device=str(self.device), slot=2, out=self._packed("pack", n, fixed_len, r2 is not None))
         t1 = time.perf_counter()
-        rec, counts = pt.route(self.util, self.world, out=self._tensor("rec", (n, pt.key_words + 2)))
-        # (the host waited for P(b) only: C(b-1) is not enqueued yet)
+        rec, _ = pt.route(self.util, self.world, out=self._tensor("rec", (n, pt.key_words + 2)), wait=False)
         t2 = time.perf_counter()
         if self.arrived is not None:
-            self._begin(b - 1)
+            self._begin(b - 1)                           # C(b-1) queues up behind P(b): no gap on the launch stream
+        counts = self.util.route_counts(self.world)     # the host waits for P(b) only
         t3 = time.perf_counter()
         got = exchange_routed(rec, counts, self.group,     # X(b) while C(b-1) runs
                               alloc=lambda rows: self._tensor(("got", b % 3), (rows, pt.key_words + 2)),
@@ -351,6 +352,118 @@ class ShardedPipeline:
             outs.append(self._finish(b - 1))
         self.i = 0
         return outs
+
+
+class LocalAlignPipeline:
+    """The multi-GPU step in its second form: every rank aligns the reads it was given; only the KEYS travel, to the
+    rank that owns them (hash mod world), and one verdict byte per read comes back (include/nimble_hip.h,
+    nimble_ctx_defer_dedup).  Against ShardedPipeline this drops the unpack, keeps the per-read records on the rank
+    that read the input, and lets the key exchange run beside the alignment of the same batch.  For batch b:
+         P(b) head + pack + route     launch stream
+         A(b) align + interning       launch stream;   X1(b) all_to_all of the key records runs beside it (RCCL)
+         D(b) owner's dedup of the received records -> verdict bytes;   X2(b) all_to_all of the verdicts
+         C(b) count with the verdicts  launch stream, enqueued behind A(b+1) so that X2(b) is never waited for
+         F(b) rows + count all-reduce  host + one small RCCL all_reduce, two batches later
+    Three call slots are open at a time.  submit(b) returns the reduced table of batch b-2; flush() drains."""
+
+    SLOTS = (0, 1, 3)
+
+    def __init__(self, lib, device, reducer, group=None, align_grid_pct=87):
+        self.nim = __import__("importlib").import_module("nimble-aligner_amd")
+        self.lib, self.device, self.reducer, self.group = lib, device, reducer, group
+        self.world = dist.get_world_size(group)
+        self.util = lib.device_context(2)
+        self.ctxs = [lib.device_context(s) for s in self.SLOTS]
+        self.comm = torch.cuda.Stream(device=device)     # see ShardedPipeline: nothing may run on the null stream
+        self.launch = torch.cuda.ExternalStream(self.ctxs[0].stream_ptr(), device=device)
+        align_grid_pct = int(os.environ.get("NIMBLE_ALIGN_GRID_PCT", align_grid_pct))
+        for c in self.ctxs:
+            c.set_option(self.nim.OPT_ALIGN_GRID_PCT, align_grid_pct)
+        self.i = 0
+        self.waiting = None      # (batch, event after X2, verdict tensor): its count is enqueued by the next submit
+        self._bufs = {}
+
+    def _tensor(self, tag, shape, dtype=torch.int64):
+        t = self._bufs.get(tag)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[tag] = t
+        return t
+
+    def _count_waiting(self):
+        """X2 + C of the batch whose owner-side dedup was enqueued by the previous submit."""
+        if self.waiting is None:
+            return
+        b, d, owner, recv_counts, counts, mine, n = self.waiting
+        self.waiting = None
+        torch.cuda.current_stream().wait_event(d)
+        dist.all_to_all_single(mine[:n], owner, output_split_sizes=list(counts), input_split_sizes=list(recv_counts),
+                               group=self.group)                                 # X2: one verdict byte per read
+        x2 = torch.cuda.Event()
+        x2.record()
+        self.launch.wait_event(x2)
+        self.ctxs[b % 3].count_verdicts(mine)
+
+    def _finish(self, b):
+        rows = self.lib.score_call_end(self.SLOTS[b % 3], raw=True)
+        return self.reducer.reduce(rows.keys, rows.counts(), rows.signature())
+
+    def submit(self, r1, r2, n, fixed_len):
+        """Feed batch i (uint8 device tensors [n, fixed_len]); returns the reduced table of batch i-2 or None."""
+        with torch.cuda.stream(self.comm):
+            return self._submit(r1, r2, n, fixed_len)
+
+    def _submit(self, r1, r2, n, fixed_len):
+        b, k = self.i, self.i % 3
+        ctx = self.ctxs[k]
+        kw = self.nim.key_words(fixed_len, r2 is not None)
+        t0 = time.perf_counter()
+        rec = self._tensor(("rec", k), (max(n, 1), kw + 2))
+        perm = self._tensor(("perm", k), (max(n, 1),), torch.int32)
+        ctx.defer_dedup(self.world, rec, perm)
+        self.lib.score_call_begin(self.SLOTS[k], r1, None, r2, None, n=n, fixed_len=fixed_len,
+                                  mem=self.nim.MEM_DEVICE)                       # P(b) A(b)
+        # X2(b-1) C(b-1): the verdict exchange waits for D(b-1), which ran before P(b); the count lands behind A(b).
+        # (Enqueued here and not at the end of submit(b-1): RCCL work is ordered on the comm stream, and the count
+        # all-reduce of F(b-3) must not queue behind an exchange that waits for A(b-1).)
+        self._count_waiting()
+        t1 = time.perf_counter()
+        counts = ctx.route_counts(self.world)                                    # the host waits for P(b) only
+        t2 = time.perf_counter()
+        got, recv_counts = exchange_routed(rec[:n], counts, self.group, staging=self.reducer.staging, with_counts=True,
+                                           alloc=lambda rows: self._tensor(("got", k), (max(rows, 1), kw + 2))[:rows])
+        x1 = torch.cuda.Event()
+        x1.record()                                                              # X1(b), beside A(b)
+        self.launch.wait_event(x1)
+        owner = self._tensor(("owner", k), (max(int(got.shape[0]), 1),), torch.uint8)[:int(got.shape[0])]
+        self.util.dedup_records(got, kw, owner)                                  # D(b)
+        d = torch.cuda.Event()
+        d.record(self.launch)
+        mine = self._tensor(("mine", k), (max(n, 1),), torch.uint8)
+        self.waiting = (b, d, owner, recv_counts, counts, mine, n)
+        t3 = time.perf_counter()
+        out = self._finish(b - 2) if b >= 2 else None                            # F(b-2)
+        t4 = time.perf_counter()
+        if _TIMING is not None:
+            for name, v in (("l_begin", t1 - t0), ("l_route_wait", t2 - t1), ("l_exchange", t3 - t2),
+                            ("l_finish", t4 - t3)):
+                _TIMING[name] = _TIMING.get(name, 0.0) + v * 1e3
+            _TIMING["steps"] = _TIMING.get("steps", 0) + 1
+        self.i += 1
+        return out
+
+    def flush(self):
+        """Drain: the reduced tables of the batches still in the pipeline, oldest first."""
+        with torch.cuda.stream(self.comm):
+            b = self.i
+            self._count_waiting()
+            outs = []
+            if b >= 2:
+                outs.append(self._finish(b - 2))
+            if b >= 1:
+                outs.append(self._finish(b - 1))
+            self.i = 0
+            return outs
 
 
 def sharded_call_packed(lib, r1, r2, n, fixed_len, device, group=None, raw=False):

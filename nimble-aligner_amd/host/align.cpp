@@ -380,7 +380,7 @@ PseudoAligner::CoercionMemo &PseudoAligner::memo_for(const reference_library::Re
 
 nimble_ctx *PseudoAligner::ctx(int slot) {
   if (slot == 0) return ctx_;
-  if (slot != 1 && slot != 2) throw Panic("PseudoAligner::ctx: slot must be 0, 1 or 2");
+  if (slot < 1 || slot > 3) throw Panic("PseudoAligner::ctx: slot must be 0..3");
   nimble_ctx *&c = extra_[slot - 1];
   // slot 1 launches on slot 0's stream (calls in flight stay in order); the utility context gets a stream of its
   // own when NIMBLE_UTIL_STREAM is set (experiment: pack / route beside the align kernel of the call in flight)

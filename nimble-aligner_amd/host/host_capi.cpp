@@ -37,8 +37,8 @@ struct nimble_library {
   reference_library::Reference ref;
   std::unique_ptr<align::PseudoAligner> index;
   std::unique_ptr<align::CallStream> stream;  // nimble_score_stream_begin .. _end
-  bool pending[2] = {false, false};  // nimble_score_call_begin without its _end yet
-  uint64_t pending_n[2] = {0, 0};
+  bool pending[4] = {false, false, false, false};  // nimble_score_call_begin without its _end yet
+  uint64_t pending_n[4] = {0, 0, 0, 0};
 };
 struct nimble_umi_rows {
   align::UmiOutput out;
@@ -141,9 +141,12 @@ void *nimble_library_index(nimble_library *l) { return l->index ? (void *)l->ind
 void *nimble_library_ctx(nimble_library *l) { return l->index ? (void *)l->index->ctx() : nullptr; }
 void *nimble_library_ctx_slot(nimble_library *l, int slot) {
   void *p = nullptr;
-  if (l->index && slot >= 0 && slot <= 2) guarded([&] { p = (void *)l->index->ctx(slot); });
+  if (l->index && slot >= 0 && slot <= 3) guarded([&] { p = (void *)l->index->ctx(slot); });
   return p;
 }
+
+// slots that may hold a call in flight (2 is the utility context)
+static bool call_slot(int slot) { return slot == 0 || slot == 1 || slot == 3; }
 
 static nimble_rows *make_rows(align::CallOutput &&o) {
   nimble_rows *r = new nimble_rows();
@@ -176,7 +179,7 @@ int nimble_score_call_begin(nimble_library *l, int slot, const uint8_t *r1, cons
                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
   return guarded([&] {
     if (!l->index) throw Panic("nimble_score_call_begin: the library has no index");
-    if (slot < 0 || slot > 1) throw Panic("nimble_score_call_begin: slot must be 0 or 1");
+    if (!call_slot(slot)) throw Panic("nimble_score_call_begin: slot must be 0, 1 or 3");
     if (l->pending[slot]) throw Panic("nimble_score_call_begin: the slot already holds a call (end it first)");
     align::ReadBatch b1, b2;
     b1.bases = r1;
@@ -198,7 +201,7 @@ int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
   *out = nullptr;
   return guarded([&] {
     if (!l->index) throw Panic("nimble_score_call_end: the library has no index");
-    if (slot < 0 || slot > 1 || !l->pending[slot]) throw Panic("nimble_score_call_end: no call was begun in this slot");
+    if (!call_slot(slot) || !l->pending[slot]) throw Panic("nimble_score_call_end: no call was begun in this slot");
     l->pending[slot] = false;
     *out = make_rows(align::end_calls(l->pending_n[slot], *l->index, l->ref, l->cfg, slot));
   });
@@ -332,7 +335,7 @@ int nimble_library_pack_slot(nimble_library *l, int slot, const uint8_t *r1, con
 int nimble_score_call_packed_begin(nimble_library *l, int slot, const nimble_packed *in, uint64_t n, uint32_t max_len) {
   return guarded([&] {
     if (!l->index) throw Panic("nimble_score_call_packed_begin: the library has no index");
-    if (slot < 0 || slot > 1) throw Panic("nimble_score_call_packed_begin: slot must be 0 or 1");
+    if (!call_slot(slot)) throw Panic("nimble_score_call_packed_begin: slot must be 0, 1 or 3");
     if (l->pending[slot]) throw Panic("nimble_score_call_packed_begin: the slot already holds a call (end it first)");
     align::begin_calls_packed(*in, n, max_len, *l->index, l->cfg, slot);
     l->pending[slot] = true;

@@ -124,7 +124,8 @@ class PseudoAligner {
   nimble_index *index() const { return index_; }
   // slot 0 is the context every call uses; slot 1 (created on first use, same launch stream) lets a second
   // call be enqueued while the first one's results are read (begin_calls / end_calls); slot 2 is a utility
-  // context for pack / route / unpack while calls are in flight on the other two (multi-GPU pipeline)
+  // context for pack / route / unpack while calls are in flight on the other two (multi-GPU pipeline); slot 3
+  // is a third call slot (the align-where-the-reads-are pipeline keeps three calls open)
   nimble_ctx *ctx(int slot = 0);
   const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
 
@@ -143,7 +144,7 @@ class PseudoAligner {
   PseudoAligner() = default;
   nimble_index *index_ = nullptr;
   nimble_ctx *ctx_ = nullptr;
-  nimble_ctx *extra_[2] = {nullptr, nullptr};  // slots 1 and 2
+  nimble_ctx *extra_[3] = {nullptr, nullptr, nullptr};  // slots 1, 2 and 3
   std::unordered_map<uint32_t, std::vector<uint32_t>> class_cache_;
   std::shared_ptr<CoercionMemo> memo_;
   bool light_rows_ = false;

@@ -74,8 +74,9 @@ class FakeDist:
         out_list[:] = everyone
 
 
+@pytest.mark.parametrize("form", ["sharded", "local"])
 @pytest.mark.parametrize("world,paired", [(2, False), (3, False), (2, True)])
-def test_sharded_pipeline_with_virtual_ranks(world, paired, monkeypatch, tmp_path):
+def test_sharded_pipeline_with_virtual_ranks(world, paired, form, monkeypatch, tmp_path):
     torch = pytest.importorskip("torch")
     names, seqs = synth.make_library(160)
     path = str(tmp_path / "lib.json")
@@ -126,17 +127,22 @@ def test_sharded_pipeline_with_virtual_ranks(world, paired, monkeypatch, tmp_pat
             torch.cuda.set_device(0)
             lib = nim.Library(path, "unstranded").build_index()
             red = nd.TableReducer(device)
-            pipe = nd.ShardedPipeline(lib, device, red)
+            pipe = (nd.ShardedPipeline if form == "sharded" else nd.LocalAlignPipeline)(lib, device, red)
             outs = []
-            # first step through the unpipelined form (as bench.py does), the rest through the pipeline
-            d1 = torch.from_numpy(batches[0][r][0]).to(device)
-            d2 = None if not paired else torch.from_numpy(batches[0][r][1]).to(device)
-            torch.cuda.synchronize()
-            outs.append(red.rows(*nd.sharded_step(lib, d1, d2, d1.shape[0], 150, device, red)))
-            for b in range(1, n_batches):
+            first = 0
+            if form == "sharded":
+                # first step through the unpipelined form (as bench.py does), the rest through the pipeline
+                d1 = torch.from_numpy(batches[0][r][0]).to(device)
+                d2 = None if not paired else torch.from_numpy(batches[0][r][1]).to(device)
+                torch.cuda.synchronize()
+                outs.append(red.rows(*nd.sharded_step(lib, d1, d2, d1.shape[0], 150, device, red)))
+                first = 1
+            keep = []
+            for b in range(first, n_batches):
                 d1 = torch.from_numpy(batches[b][r][0]).to(device)
                 d2 = None if not paired else torch.from_numpy(batches[b][r][1]).to(device)
                 torch.cuda.synchronize()
+                keep.append((d1, d2))   # the reads of a call in flight are borrowed
                 got = pipe.submit(d1, d2, d1.shape[0], 150)
                 if got is not None:
                     outs.append(red.rows(*got))
