@@ -195,6 +195,10 @@ int nimble_call_packed(nimble_ctx *, const nimble_align_params *, const nimble_p
 int nimble_route_records(nimble_ctx *, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
                          uint64_t *counts);
 int nimble_unpack_records(nimble_ctx *, const uint64_t *records, uint64_t n, const nimble_packed *out);
+/* ... or run the call straight off the received records (no unpack; the records must stay alive and untouched until
+ * the first getter): nimble_call_packed semantics, reads in record order. */
+int nimble_call_records(nimble_ctx *, const nimble_align_params *, const uint64_t *records, uint64_t n,
+                        uint32_t max_len, int paired);
 
 /* ---- multi-GPU, second form: align where the reads are.  Only the keys travel: the rank that owns a key (hash
  *      mod world) sees every copy of it and answers one byte per copy -- 1 = this copy stands for the key in

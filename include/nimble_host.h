@@ -121,6 +121,9 @@ int nimble_library_pack_slot(nimble_library *, int slot, const uint8_t *r1, cons
                              const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                              const nimble_packed *out);
 int nimble_score_call_packed_begin(nimble_library *, int slot, const nimble_packed *in, uint64_t n, uint32_t max_len);
+/* the same straight off received exchange records (device, n rows of key_words + 2 u64; nimble_call_records) */
+int nimble_score_call_records_begin(nimble_library *, int slot, const uint64_t *records, uint64_t n, uint32_t max_len,
+                                    int paired);
 /* get_error_checked_fastq_readers + score::call */
 int nimble_score_call_fastq(nimble_library *, const char *r1_path, const char *r2_path, nimble_rows **out);
 void nimble_rows_free(nimble_rows *);

@@ -91,6 +91,7 @@ HIP_SYMBOLS = [
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
+    "nimble_call_records",
 ]
 
 
@@ -145,6 +146,7 @@ def hip_lib():
         L.nimble_route_counts.argtypes = [vp, vp]
         L.nimble_dedup_records.argtypes = [vp, vp, u64, u32, vp]
         L.nimble_count_verdicts.argtypes = [vp, vp]
+        L.nimble_call_records.argtypes = [vp, C.POINTER(AlignParams), vp, u64, u32, i32]
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
         _hip = L
@@ -451,7 +453,8 @@ HOST_SYMBOLS = [
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
-    "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
+    "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
+    "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
 ]
 
@@ -508,6 +511,7 @@ def host_lib():
         L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
         L.nimble_library_pack_slot.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
         L.nimble_score_call_packed_begin.argtypes = [vp, i32, C.POINTER(NimblePacked), u64, u32]
+        L.nimble_score_call_records_begin.argtypes = [vp, i32, vp, u64, u32, i32]
         L.nimble_rows_signature.argtypes = [vp]
         L.nimble_rows_signature.restype = u64
         L.nimble_rows_counts.argtypes = [vp, vp]
@@ -902,6 +906,15 @@ class Library:
         stay alive until then."""
         st = pt.as_struct()
         _hcheck(host_lib().nimble_score_call_packed_begin(self.h, slot, C.byref(st), pt.n, pt.max_len))
+
+    def score_call_records_begin(self, slot, rec, max_len, paired):
+        """The same straight off received exchange records ([n, key_words + 2] int64 device tensor; it must stay
+        alive and untouched until score_call_end(slot))."""
+        assert rec.is_contiguous()
+        self._rec_keep = getattr(self, "_rec_keep", {})
+        self._rec_keep[slot] = rec
+        _hcheck(host_lib().nimble_score_call_records_begin(self.h, slot, C.c_void_p(rec.data_ptr()),
+                                                           int(rec.shape[0]), max_len, int(bool(paired))))
 
     def score_call_packed(self, pt, raw=False):
         """Second half of the split call: score::call from packed arrays (possibly received from other ranks)."""

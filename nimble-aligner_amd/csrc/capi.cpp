@@ -823,7 +823,7 @@ static int check_read_args(const uint8_t *r1, const uint64_t *r1_off, const uint
 // Buffers and tables of one call over n reads.  `ext` (may be NULL) supplies caller-owned device arrays for the
 // packed form (keys, lengths, key hash, prefilter verdicts) instead of the context's own.
 static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, bool paired, uint32_t max_len,
-                      const nimble_packed *ext) {
+                      const nimble_packed *ext, const uint64_t *records = nullptr) {
   const int nm = paired ? 2 : 1;
   const uint32_t kw = (max_len * (uint32_t)nm + 31u) / 32u;
   // the walk keeps every key of a tile in LDS; one workgroup may take up to 160 KiB on gfx950
@@ -841,14 +841,14 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   auto need = [&](DevBuf &b, size_t bytes) {
     if (rc == NIMBLE_OK) rc = b.ensure(bytes, &c->bytes);
   };
-  if (!ext) {
+  if (!ext && !records) {
     need(c->b_keys, nn * kw * 8);
     need(c->b_hash, nn * 8);
   }
   need(c->b_slot, nn * 4);
   need(c->b_counted, nn);
   for (int m = 0; m < 2; ++m) {
-    if (!ext || (m == 1 && !ext->len[1])) {
+    if (!records && (!ext || (m == 1 && !ext->len[1]))) {
       need(c->b_len[m], nn * 4);
       need(c->b_pre[m], nn);
     }
@@ -885,14 +885,16 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   rc = ensure_min_cov(c, p->score_percent, max_len);
   if (rc != NIMBLE_OK) return rc;
 
-  cb.keys = ext ? ext->keys : c->b_keys.as<uint64_t>();
-  cb.key_hash = ext ? ext->hash : c->b_hash.as<uint64_t>();
+  cb.rec = records;  // the call reads keys, lengths, prefilter verdicts and hashes from exchange records
+  cb.rec_words = kw + 2;
+  cb.keys = records ? nullptr : ext ? ext->keys : c->b_keys.as<uint64_t>();
+  cb.key_hash = records ? nullptr : ext ? ext->hash : c->b_hash.as<uint64_t>();
   cb.slot = c->b_slot.as<uint32_t>();
   cb.counted = c->b_counted.as<uint8_t>();
   for (int m = 0; m < 2; ++m) {
     const bool use_ext = ext && ext->len[m];
-    cb.len[m] = use_ext ? ext->len[m] : c->b_len[m].as<uint32_t>();
-    cb.pre[m] = use_ext ? ext->pre[m] : c->b_pre[m].as<uint8_t>();
+    cb.len[m] = records ? nullptr : use_ext ? ext->len[m] : c->b_len[m].as<uint32_t>();
+    cb.pre[m] = records ? nullptr : use_ext ? ext->pre[m] : c->b_pre[m].as<uint8_t>();
     cb.reason[m] = c->b_reason[m].as<uint8_t>();
     cb.score[m] = c->b_score[m].as<uint32_t>();
     cb.mism[m] = c->b_mism[m].as<uint32_t>();
@@ -1122,6 +1124,20 @@ int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, co
   launch_records_unpack(c->stream, records, v);
   HIPCHK(hipGetLastError());
   return NIMBLE_OK;
+}
+
+int nimble_call_records(nimble_ctx *c, const nimble_align_params *p, const uint64_t *records, uint64_t n,
+                        uint32_t max_len, int paired) {
+  if (!c || !p || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_call_records: NULL argument");
+  if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_call_records: more than 2^32 reads in one call");
+  if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call_records: bad max_len");
+  HIPCHK(hipSetDevice(c->ix->device));
+  static const uint64_t none[1] = {0};
+  int rc = setup_call(c, p, n, paired != 0, max_len, nullptr, n ? records : none);
+  if (rc) return rc;
+  c->cb.fuse_count = paired ? 0u : 1u;
+  c->skip_pack = true;
+  return start_call(c);
 }
 
 // ---- align-where-the-reads-are form of the multi-GPU step -----------------------------------------------------
@@ -1483,6 +1499,7 @@ int nimble_read_align_len(nimble_ctx *c, int mate, uint32_t *align_len, uint64_t
     memset(align_len, 0, n * 4);
     return NIMBLE_OK;
   }
+  if (c->cb.rec) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: the call read exchange records (lengths are in them)");
   HIPCHK(hipMemcpy(align_len, c->cb.alen[mate], n * 4, hipMemcpyDeviceToHost));
   return NIMBLE_OK;
 }

@@ -45,6 +45,8 @@ struct CallBuffers {
   uint32_t key_words;   // words per packed key (R1 ++ R2)
   uint32_t paired;
   uint64_t *keys;       // [key_words][n]
+  const uint64_t *rec;  // may be non-NULL instead of keys / len / pre / key_hash: exchange records, one row per read
+  uint32_t rec_words;   // key_words + 2
   uint32_t *len[2];     // bases per mate (the dedup key)
   uint32_t *alen[2];    // bases per mate that are aligned: == len unless the call trims for quality (BAM mode)
   const uint8_t *skip[2];   // per mate, may be NULL: SKIP_ALIGN dummies (align.rs:527-528)

@@ -246,6 +246,27 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
 // k_align helpers
 // ---------------------------------------------------------------------------------------------
 
+// A call may take its reads straight from exchange records (cb.rec: rows of rec_words = key_words + 2 u64 =
+// [key words..., key hash, len0 | len1 << 16 | pre0 << 32 | pre1 << 40]) instead of the packed arrays.
+__device__ __forceinline__ uint64_t rd_key(const CallBuffers &cb, uint32_t w, uint64_t r) {
+  return cb.rec ? cb.rec[r * cb.rec_words + w] : cb.keys[(uint64_t)w * cb.key_stride + r];
+}
+__device__ __forceinline__ uint64_t rd_meta(const CallBuffers &cb, uint64_t r) {
+  return cb.rec[r * cb.rec_words + cb.key_words + 1];
+}
+__device__ __forceinline__ uint32_t rd_len(const CallBuffers &cb, int m, uint64_t r) {
+  return cb.rec ? (uint32_t)((rd_meta(cb, r) >> (16 * m)) & 0xFFFF) : cb.len[m][r];
+}
+__device__ __forceinline__ uint32_t rd_alen(const CallBuffers &cb, int m, uint64_t r) {
+  return cb.rec ? (uint32_t)((rd_meta(cb, r) >> (16 * m)) & 0xFFFF) : cb.alen[m][r];
+}
+__device__ __forceinline__ uint32_t rd_pre(const CallBuffers &cb, int m, uint64_t r) {
+  return cb.rec ? (uint32_t)((rd_meta(cb, r) >> (32 + 8 * m)) & 0xFF) : cb.pre[m][r];
+}
+__device__ __forceinline__ uint64_t rd_hash(const CallBuffers &cb, uint64_t r) {
+  return cb.rec ? cb.rec[r * cb.rec_words + cb.key_words] : cb.key_hash[r];
+}
+
 struct Lane {
   const uint64_t *rd;  // LDS column holding the packed key (stride ALIGN_BLOCK words)
   uint32_t *lc;        // LDS column of visited colours (stride ALIGN_BLOCK)
@@ -784,14 +805,19 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
     uint64_t seedv = ~0ULL;
     if (r_own < n) {
-      const uint32_t k0 = cb.len[0][r_own];
-      const uint32_t l1 = nm == 2 ? cb.len[1][r_own] : 0u;
+      const uint32_t k0 = rd_len(cb, 0, r_own);
+      const uint32_t l1 = nm == 2 ? rd_len(cb, 1, r_own) : 0u;
       const uint32_t nw = (k0 + l1 + 31u) >> 5;
-      const uint32_t l0 = cb.alen[0][r_own];  // bases of mate 0 that are aligned
-      for (uint32_t w = 0; w < kw; ++w)
-        col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
+      const uint32_t l0 = rd_alen(cb, 0, r_own);  // bases of mate 0 that are aligned
+      if (cb.rec) {
+        const uint64_t *row = cb.rec + r_own * cb.rec_words;
+        for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? row[w] : 0ULL;
+      } else {
+        for (uint32_t w = 0; w < kw; ++w)
+          col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
+      }
       col[kw * ALIGN_BLOCK] = 0ULL;
-      if (cb.pre[0][r_own] == R_TODO && l0 >= KMER) {
+      if (rd_pre(cb, 0, r_own) == R_TODO && l0 >= KMER) {
         uint32_t nd = 0, of = 0;
         ln.rd = col;
         if (probe_direct(ix, ln, 0u, 0u, nd, of)) {
@@ -837,10 +863,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
     uint32_t L[2] = {0, 0};   // aligned bases per mate
     uint32_t mate1_at = 0;    // where mate 1 starts inside the key (the untrimmed length of mate 0)
     if (active) {
-      L[0] = cb.alen[0][r];
+      L[0] = rd_alen(cb, 0, r);
       if (nm == 2) {
-        L[1] = cb.alen[1][r];
-        mate1_at = cb.len[0][r];
+        L[1] = rd_alen(cb, 1, r);
+        mate1_at = rd_len(cb, 0, r);
       }
     }
     bool any_walk = false;
@@ -853,7 +879,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
       mres.base = 0;
       mres.mask = 0;
       if (active) {
-        uint32_t pre = cb.pre[m][r];
+        uint32_t pre = rd_pre(cb, m, r);
         if (pre != R_TODO) {
           reason = pre;
           if (m == 0) c_pre++;
@@ -1074,10 +1100,11 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
   }
   // the dedup scope is the segment (one UMI = one score::call): it is part of the key
   const uint32_t seg = cb.seg ? cb.seg[i] : 0u;
-  const uint64_t h = cb.seg ? mix64(cb.key_hash[i] ^ ((uint64_t)seg * 0x9E3779B97F4A7C15ULL)) : cb.key_hash[i];
+  const uint64_t h0 = rd_hash(cb, i);
+  const uint64_t h = cb.seg ? mix64(h0 ^ ((uint64_t)seg * 0x9E3779B97F4A7C15ULL)) : h0;
   const uint32_t tag = (uint32_t)(h >> 32) | 1u;
   const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)i;
-  const uint32_t total = cb.len[0][i] + (cb.paired ? cb.len[1][i] : 0u);
+  const uint32_t total = rd_len(cb, 0, i) + (cb.paired ? rd_len(cb, 1, i) : 0u);
   const uint32_t nw = (total + 31u) >> 5;
   uint32_t pos = __umulhi((uint32_t)h, cb.dedup_slots);  // low hash half picks the slot, high half is the tag
   for (;;) {
@@ -1090,8 +1117,8 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
     }
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t j = (uint32_t)cur;
-      bool same = (cb.len[0][j] + (cb.paired ? cb.len[1][j] : 0u)) == total && (!cb.seg || cb.seg[j] == seg);
-      for (uint32_t w = 0; same && w < nw; ++w) same = cb.keys[(uint64_t)w * cb.key_stride + i] == cb.keys[(uint64_t)w * cb.key_stride + j];
+      bool same = (rd_len(cb, 0, j) + (cb.paired ? rd_len(cb, 1, j) : 0u)) == total && (!cb.seg || cb.seg[j] == seg);
+      for (uint32_t w = 0; same && w < nw; ++w) same = rd_key(cb, w, i) == rd_key(cb, w, j);
       if (same) {
         atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
         break;

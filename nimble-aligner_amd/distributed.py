@@ -266,9 +266,11 @@ class ShardedPipeline:
         # stream waits for whatever is in flight on the library's launch stream (measured: even a .tolist() of
         # eight numbers takes the length of the running call), a side stream does not
         self.comm = torch.cuda.Stream(device=device)
+        self.launch = torch.cuda.ExternalStream(lib.device_context(0).stream_ptr(), device=device)
         align_grid_pct = int(os.environ.get("NIMBLE_ALIGN_GRID_PCT", align_grid_pct))
         for slot in (0, 1):  # leave room beside the persistent align grid for RCCL's kernels
             lib.device_context(slot).set_option(self.nim.OPT_ALIGN_GRID_PCT, align_grid_pct)
+        self.from_records = os.environ.get("NIMBLE_UNPACK_RECORDS") is None
         self.i = 0
         self.arrived = None        # (records, key_words, max_len, paired) of batch i-1, exchanged, not yet begun
         self.inflight = {}         # slot -> shard tensors of the call in flight (kept alive)
@@ -289,9 +291,15 @@ class ShardedPipeline:
         return pt
 
     def _begin(self, b):
-        got, kw, max_len, paired = self.arrived
+        got, kw, max_len, paired, arrived_ev = self.arrived
         self.arrived = None
         slot = b % 2
+        self.launch.wait_event(arrived_ev)   # the launch stream, not the host, waits for the exchange
+        if self.from_records:
+            # the call reads the received records as they are (no unpack pass)
+            self.lib.score_call_records_begin(slot, got, max_len, paired)
+            self.inflight[slot] = got
+            return
         shard = self.nim.PackedTensors.unpack(self.lib.device_context(slot), got, kw, max_len, paired,
                                               out=self._packed(("shard", b % 3), int(got.shape[0]), max_len, paired))
         self.lib.score_call_packed_begin(slot, shard)
@@ -313,24 +321,27 @@ class ShardedPipeline:
         t0 = time.perf_counter()
         pt = self.lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=self.nim.MEM_DEVICE,
                            device=str(self.device), slot=2, out=self._packed("pack", n, fixed_len, r2 is not None))
-        t1 = time.perf_counter()
         rec, _ = pt.route(self.util, self.world, out=self._tensor("rec", (n, pt.key_words + 2)), wait=False)
-        t2 = time.perf_counter()
+        t1 = time.perf_counter()
         if self.arrived is not None:
             self._begin(b - 1)                           # C(b-1) queues up behind P(b): no gap on the launch stream
-        counts = self.util.route_counts(self.world)     # the host waits for P(b) only
+        t2 = time.perf_counter()
+        # F(b-2) before X(b) is enqueued: RCCL work is ordered on the comm stream, and the small count all-reduce must
+        # not queue behind the record exchange
+        out = self._finish(b - 2) if b >= 2 else None
         t3 = time.perf_counter()
-        got = exchange_routed(rec, counts, self.group,     # X(b) while C(b-1) runs
+        counts = self.util.route_counts(self.world)     # the host waits for P(b) only
+        t4 = time.perf_counter()
+        got = exchange_routed(rec, counts, self.group,     # X(b) while C(b-1) runs; nobody on the host waits for it
                               alloc=lambda rows: self._tensor(("got", b % 3), (rows, pt.key_words + 2)),
                               staging=self.reducer.staging)
-        torch.cuda.current_stream().synchronize()
-        t4 = time.perf_counter()
-        self.arrived = (got, pt.key_words, pt.max_len, pt.paired)
-        out = self._finish(b - 2) if b >= 2 else None
+        ev = torch.cuda.Event()
+        ev.record()
+        self.arrived = (got, pt.key_words, pt.max_len, pt.paired, ev)
         t5 = time.perf_counter()
         if _TIMING is not None:
-            for k, v in (("p_pack", t1 - t0), ("p_route_wait", t2 - t1), ("p_begin", t3 - t2), ("p_exchange", t4 - t3),
-                         ("p_finish", t5 - t4)):
+            for k, v in (("p_pack", t1 - t0), ("p_begin", t2 - t1), ("p_finish", t3 - t2), ("p_route_wait", t4 - t3),
+                         ("p_exchange", t5 - t4)):
                 _TIMING[k] = _TIMING.get(k, 0.0) + v * 1e3
             _TIMING["steps"] = _TIMING.get("steps", 0) + 1
         self.i += 1
@@ -428,6 +439,7 @@ class LocalAlignPipeline:
         # all-reduce of F(b-3) must not queue behind an exchange that waits for A(b-1).)
         self._count_waiting()
         t1 = time.perf_counter()
+        out = self._finish(b - 2) if b >= 2 else None                            # F(b-2), before X1(b) is enqueued
         counts = ctx.route_counts(self.world)                                    # the host waits for P(b) only
         t2 = time.perf_counter()
         got, recv_counts = exchange_routed(rec[:n], counts, self.group, staging=self.reducer.staging, with_counts=True,
@@ -442,8 +454,7 @@ class LocalAlignPipeline:
         mine = self._tensor(("mine", k), (max(n, 1),), torch.uint8)
         self.waiting = (b, d, owner, recv_counts, counts, mine, n)
         t3 = time.perf_counter()
-        out = self._finish(b - 2) if b >= 2 else None                            # F(b-2)
-        t4 = time.perf_counter()
+        t4 = t3
         if _TIMING is not None:
             for name, v in (("l_begin", t1 - t0), ("l_route_wait", t2 - t1), ("l_exchange", t3 - t2),
                             ("l_finish", t4 - t3)):

@@ -454,6 +454,12 @@ void begin_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, P
   check_rc(nimble_call_packed(index.ctx(slot), &p, &in, n, max_len), "nimble_call_packed");
 }
 
+void begin_calls_records(const uint64_t *records, uint64_t n, uint32_t max_len, bool paired, PseudoAligner &index,
+                         const AlignFilterConfig &config, int slot) {
+  nimble_align_params p = make_params(config);
+  check_rc(nimble_call_records(index.ctx(slot), &p, records, n, max_len, paired ? 1 : 0), "nimble_call_records");
+}
+
 void pack_reads(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &index, const AlignFilterConfig &config,
                 const nimble_packed &out, int slot) {
   if (mates && mates->n != seqs.n)

@@ -343,6 +343,18 @@ int nimble_score_call_packed_begin(nimble_library *l, int slot, const nimble_pac
   });
 }
 
+int nimble_score_call_records_begin(nimble_library *l, int slot, const uint64_t *records, uint64_t n, uint32_t max_len,
+                                    int paired) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_records_begin: the library has no index");
+    if (!call_slot(slot)) throw Panic("nimble_score_call_records_begin: slot must be 0, 1 or 3");
+    if (l->pending[slot]) throw Panic("nimble_score_call_records_begin: the slot already holds a call (end it first)");
+    align::begin_calls_records(records, n, max_len, paired != 0, *l->index, l->cfg, slot);
+    l->pending[slot] = true;
+    l->pending_n[slot] = n;
+  });
+}
+
 int nimble_score_call_packed(nimble_library *l, const nimble_packed *in, uint64_t n, uint32_t max_len,
                              nimble_rows **out) {
   *out = nullptr;

@@ -248,6 +248,8 @@ class CallStream {
 void pack_reads(const ReadBatch &sequences, const ReadBatch *mate_sequences, PseudoAligner &index,
                 const AlignFilterConfig &config, const nimble_packed &out, int slot = 0);
 // first half of get_calls_packed (the second half is end_calls on the same slot)
+void begin_calls_records(const uint64_t *records, uint64_t n, uint32_t max_len, bool paired, PseudoAligner &index,
+                         const AlignFilterConfig &config, int slot = 0);  // the same, straight off exchange records
 void begin_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
                         const AlignFilterConfig &config, int slot);
 CallOutput get_calls_packed(const nimble_packed &in, uint64_t n, uint32_t max_len, PseudoAligner &index,
