@@ -321,7 +321,9 @@ class ShardedPipeline:
         t0 = time.perf_counter()
         pt = self.lib.pack(r1, None, r2, None, n=n, fixed_len=fixed_len, max_len=fixed_len, mem=self.nim.MEM_DEVICE,
                            device=str(self.device), slot=2, out=self._packed("pack", n, fixed_len, r2 is not None))
-        rec, _ = pt.route(self.util, self.world, out=self._tensor("rec", (n, pt.key_words + 2)), wait=False)
+        # two send buffers: X(b-1) may still be reading the other one (the launch stream waits for X(b-1) at the start
+        # of C(b-1), i.e. before the routing of batch b+1 writes this buffer again)
+        rec, _ = pt.route(self.util, self.world, out=self._tensor(("rec", b % 2), (n, pt.key_words + 2)), wait=False)
         t1 = time.perf_counter()
         if self.arrived is not None:
             self._begin(b - 1)                           # C(b-1) queues up behind P(b): no gap on the launch stream
