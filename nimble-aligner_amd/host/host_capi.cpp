@@ -202,8 +202,9 @@ int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
   return guarded([&] {
     if (!l->index) throw Panic("nimble_score_call_end: the library has no index");
     if (!call_slot(slot) || !l->pending[slot]) throw Panic("nimble_score_call_end: no call was begun in this slot");
-    l->pending[slot] = false;
+    // (a refused end -- e.g. a deferred-dedup call whose verdicts are not in yet -- leaves the slot open)
     *out = make_rows(align::end_calls(l->pending_n[slot], *l->index, l->ref, l->cfg, slot));
+    l->pending[slot] = false;
   });
 }
 

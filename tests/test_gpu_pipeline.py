@@ -433,9 +433,20 @@ def test_device_routing_of_exchange_records(synth_lib, paired):
             a = part[torch.argsort(part[:, pt.key_words], stable=True)]
             b = want[torch.argsort(want[:, pt.key_words], stable=True)]
             assert torch.equal(torch.sort(a.reshape(-1))[0], torch.sort(b.reshape(-1))[0])
-            shard = nim.PackedTensors.unpack(ctx, part.contiguous(), pt.key_words, pt.max_len, pt.paired)
-            for f, c in lib.score_call_packed(shard):
+            part = part.contiguous()
+            shard = nim.PackedTensors.unpack(ctx, part, pt.key_words, pt.max_len, pt.paired)
+            rows_packed = lib.score_call_packed(shard)
+            for f, c in rows_packed:
                 merged[tuple(f)] = merged.get(tuple(f), 0) + c
+            # nimble_call_records: the same call straight off the records -- same rows, same per-read records
+            ctx.n = int(part.shape[0])
+            want_recs = [ctx.read_records(m) for m in range(2 if paired else 1)]
+            lib.score_call_records_begin(0, part, pt.max_len, pt.paired)
+            assert lib.score_call_end(0) == rows_packed
+            for m, w in enumerate(want_recs):
+                got_recs = ctx.read_records(m)
+                for k in w:
+                    assert np.array_equal(got_recs[k], w[k]), (world, rank, m, k)
         assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
 
 
@@ -471,3 +482,105 @@ def test_sharded_pipeline_single_rank_rccl(synth_lib, tmp_path):
         assert red.rows(*nd.sharded_step(lib, dev[0], None, batches[0].shape[0], 150, device, red)) == direct[0]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
+    # align-where-the-reads-are (nimble_ctx_defer_dedup ... nimble_count_verdicts) with three ranks played by the three
+    # call slots of one library and the exchange done by slicing: the shares add up to the direct call over the union,
+    # the per-read records are those of a plain local call, and exactly one copy per counted key carries `counted`
+    torch = pytest.importorskip("torch")
+    path, seqs = synth_lib
+    lib = nim.Library(path, "unstranded").build_index()
+    world, slots = 3, (0, 1, 3)
+    util = lib.device_context(2)
+    reads = []
+    for r in range(world):
+        n = 20_000 + 777 * r
+        if paired:
+            a, b = synth.make_reads(seqs, n, paired=True, seed=900 + r)
+        else:
+            a, b = synth.make_reads(seqs, n, seed=900 + r), None
+        reads.append([a.copy(), None if b is None else b.copy()])
+    rng = np.random.default_rng(3)
+    for _ in range(3000):   # copies across and inside ranks
+        x, y = rng.integers(0, world, size=2)
+        i, j = rng.integers(0, reads[x][0].shape[0]), rng.integers(0, reads[y][0].shape[0])
+        reads[y][0][j] = reads[x][0][i]
+        if paired:
+            reads[y][1][j] = reads[x][1][i]
+    u1 = np.concatenate([x[0] for x in reads])
+    o = synth.fixed_offsets(u1.shape[0], 150)
+    if paired:
+        u2 = np.concatenate([x[1] for x in reads])
+        direct = lib.score_call(u1.reshape(-1), o, u2.reshape(-1), o)
+    else:
+        direct = lib.score_call(u1.reshape(-1), None, n=u1.shape[0], fixed_len=150)
+    # what a plain local call says about every read
+    plain = []
+    for r in range(world):
+        a, b = reads[r]
+        lib.score_call(a.reshape(-1), None, None if b is None else b.reshape(-1), None, n=a.shape[0], fixed_len=150)
+        c = lib.device_context()
+        c.n = a.shape[0]
+        plain.append([c.read_records(m) for m in range(2 if paired else 1)])
+    kw = nim.key_words(150, paired)
+    dev, rec, perm, counts = [], [], [], []
+    for r in range(world):
+        a, b = reads[r]
+        n = a.shape[0]
+        d1 = torch.from_numpy(a).to("cuda:0")
+        d2 = None if b is None else torch.from_numpy(b).to("cuda:0")
+        torch.cuda.synchronize()
+        dev.append((d1, d2))
+        rec.append(torch.empty((n, kw + 2), dtype=torch.int64, device="cuda:0"))
+        perm.append(torch.empty((n,), dtype=torch.int32, device="cuda:0"))
+        ctx = lib.device_context(slots[r])
+        ctx.defer_dedup(world, rec[r], perm[r])
+        lib.score_call_begin(slots[r], d1, None, d2, None, n=n, fixed_len=150, mem=nim.MEM_DEVICE)
+        counts.append(ctx.route_counts(world))
+        assert sum(counts[r]) == n
+    # the getters refuse to run before the verdicts are in
+    with pytest.raises(nim.Panic):
+        lib.score_call_end(slots[0])
+    lib.device_context(slots[0]).synchronize()
+    starts = [np.concatenate([[0], np.cumsum(c)]) for c in counts]
+    verdict_back = [[None] * world for _ in range(world)]
+    for owner in range(world):
+        parts = [rec[r][starts[r][owner]:starts[r][owner + 1]] for r in range(world)]
+        got = torch.cat(parts).contiguous()
+        verdict = torch.empty((max(got.shape[0], 1),), dtype=torch.uint8, device="cuda:0")[:got.shape[0]]
+        util.dedup_records(got, kw, verdict)
+        util.synchronize()
+        lo = 0
+        for r in range(world):
+            m = parts[r].shape[0]
+            verdict_back[r][owner] = verdict[lo:lo + m].clone()
+            lo += m
+    merged, counted_total = {}, 0
+    for r in range(world):
+        mine = torch.cat(verdict_back[r]).contiguous()
+        torch.cuda.synchronize()
+        ctx = lib.device_context(slots[r])
+        ctx.count_verdicts(mine)
+        if r == 0:
+            # score_call_end was refused above and left the slot open on the host side
+            pass
+        for f, c in lib.score_call_end(slots[r]):
+            merged[tuple(f)] = merged.get(tuple(f), 0) + c
+        ctx.n = reads[r][0].shape[0]
+        for m in range(2 if paired else 1):
+            got_recs = ctx.read_records(m)
+            for k in ("reason", "score", "mismatches", "cls"):
+                assert np.array_equal(got_recs[k], plain[r][m][k]), (r, m, k)
+        counted_total += int(ctx.read_records(0)["counted"].sum())
+    assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in direct]
+    assert counted_total == sum(c for _, c in direct)
+    # arming needs a call whose classes follow from the key: paired reads with offsets are refused
+    ctx = lib.device_context(0)
+    ctx.defer_dedup(world, rec[0], perm[0])
+    a = reads[0][0]
+    oo = synth.fixed_offsets(a.shape[0], 150)
+    with pytest.raises(nim.Panic):
+        lib.score_call(a.reshape(-1), oo, a.reshape(-1), oo)
+    assert lib.score_call(a.reshape(-1), None, n=a.shape[0], fixed_len=150)   # disarmed again: a plain call works
