@@ -75,8 +75,8 @@ class FakeDist:
 
 
 @pytest.mark.parametrize("form", ["sharded", "local"])
-@pytest.mark.parametrize("world,paired", [(2, False), (3, False), (2, True)])
-def test_sharded_pipeline_with_virtual_ranks(world, paired, form, monkeypatch, tmp_path):
+@pytest.mark.parametrize("world,paired,scale", [(2, False, 1), (3, False, 1), (2, True, 1), (2, False, 50)])
+def test_sharded_pipeline_with_virtual_ranks(world, paired, scale, form, monkeypatch, tmp_path):
     torch = pytest.importorskip("torch")
     names, seqs = synth.make_library(160)
     path = str(tmp_path / "lib.json")
@@ -90,13 +90,13 @@ def test_sharded_pipeline_with_virtual_ranks(world, paired, form, monkeypatch, t
     for b in range(n_batches):
         per_rank = []
         for r in range(world):
-            n = 6000 + 500 * r + 300 * b
+            n = (6000 + 500 * r + 300 * b) * scale   # scale 50: exchanges long enough to overlap the next batch
             if paired:
                 r1, r2 = synth.make_reads(seqs, n, paired=True, seed=1000 + 10 * b + r)
             else:
                 r1, r2 = synth.make_reads(seqs, n, seed=1000 + 10 * b + r), None
             per_rank.append([r1.copy(), None if r2 is None else r2.copy()])
-        for _ in range(400):   # cross-rank duplicates inside the step
+        for _ in range(400 * scale):   # cross-rank duplicates inside the step
             a, c = rng.integers(0, world, size=2)
             i, j = rng.integers(0, per_rank[a][0].shape[0]), rng.integers(0, per_rank[c][0].shape[0])
             per_rank[c][0][j] = per_rank[a][0][i]
