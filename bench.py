@@ -104,7 +104,7 @@ def main():
     ctx.set_counters(True)
     rows = step()
     ctx.n = n
-    counters = ctx.counters() if world == 1 else None
+    counters = ctx.counters()   # multi-GPU: of the shard this rank received (statistically the same reads)
     ctx.set_counters(False)
 
     depth = args.depth if not sharded else 1
@@ -209,20 +209,21 @@ def main():
         "device_reads_per_s": n / (stage["total"] / 1000.0) if stage["total"] > 0 else None,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         # ---- roofline of the dominant kernel (k_align): algorithmic bytes of one launch / its duration
         P, U, E = counters["probes"], counters["nodes"], counters["class_entries"]
         hit = counters["seeded"]
         key_bytes = 8 * ((L + 31) // 32)
-        align_bytes = n * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n
-        pipe_bytes = n * L + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n  # SURVEY 8(d) formula
+        n_call = int(counters["reads"]) if sharded else n   # reads of the launch the counters describe
+        align_bytes = n_call * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n_call
+        pipe_bytes = n_call * L + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n_call
         align_s = stage["align"] / 1000.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reads") == n and tj.get("features") == args.features:
+                if tj.get("reads") == n and tj.get("features") == args.features and not sharded:
                     traffic = tj.get("k_align_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -250,8 +251,8 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": align_bytes,
             "kernel_ms": stage["align"],
-            "bytes_per_read": align_bytes / n,
-            "pipeline": {"algorithmic_bytes_per_read": pipe_bytes / n,
+            "bytes_per_read": align_bytes / max(n_call, 1),
+            "pipeline": {"algorithmic_bytes_per_read": pipe_bytes / max(n_call, 1),
                          "achieved_GBps": pipe_bytes / (stage["total"] / 1000.0) / 1e9,
                          "frac": pipe_bytes / (stage["total"] / 1000.0) / 1e9 / HBM_PEAK_GBPS},
             "counters": {"probes": P, "nodes": U, "class_entries": E, "seeded": hit},
@@ -259,7 +260,7 @@ def main():
             "frac_of_stream_copy": align_bytes / align_s / 1e9 / stream_copy_gbps,
         }
         # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same reads
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:
             from oracle import oracle as ora
             S = min(args.cpu_sample, n)
             sample = reads[:S].cpu().numpy()
