@@ -126,6 +126,16 @@ struct nimble_ctx {
   double min_cov_percent = -1.0;
   uint32_t min_cov_len = 0;
   DevBuf b_out_c1, b_out_c2, b_out_cnt, b_out_seg, b_out_rep;
+  // The results the host reads after every call (state words, compacted histogram) are written by the kernels
+  // straight into page-locked host memory: a device-to-host copy of a few kB is a blit KERNEL, and behind the
+  // persistent align grid of the next call in flight it waited ~1.3 ms for a CU (tools/end_probe.py).
+  struct HostOut {
+    void *base = nullptr;
+    uint64_t cap = 0;  // entries
+    uint32_t *c1 = nullptr, *c2 = nullptr, *seg = nullptr, *rep = nullptr;
+    uint64_t *cnt = nullptr;
+  } hout;
+  bool out_pinned = false;  // the last compaction went to hout
   // BAM-mode extras (nimble_call_ex)
   DevBuf b_route;  // scratch of nimble_route_records
   // align-where-the-reads-are form (nimble_ctx_defer_dedup): the next call routes its keys and stops before dedup
@@ -189,6 +199,7 @@ struct nimble_ctx {
       for (auto &e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     if (p_state) (void)hipHostFree(p_state);
+    if (hout.base) (void)hipHostFree(hout.base);
     if (p_dyn) (void)hipHostFree(p_dyn);
     if (defer.ev_route) (void)hipEventDestroy(defer.ev_route);
     if (defer.p_counts) (void)hipHostFree(defer.p_counts);
@@ -286,30 +297,56 @@ int ensure_min_cov(nimble_ctx *c, double percent, uint32_t max_len) {
   return NIMBLE_OK;
 }
 
-// ev[6] marks the end of everything enqueued for the call so far
+// ev[6] marks the end of everything enqueued for the call so far; the state words are published to the host first
 int mark_done(nimble_ctx *c) {
+  launch_publish_state(c->stream, c->b_state.as<uint64_t>(), c->p_state);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[6], c->stream));
   return NIMBLE_OK;
 }
 
 int fetch_state(nimble_ctx *c) {
-  HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev[6], 0));
-  HIPCHK(hipMemcpyAsync(c->p_state, c->b_state.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
-  HIPCHK(hipStreamSynchronize(c->copy_stream));
+  HIPCHK(hipEventSynchronize(c->ev[6]));
   std::copy(c->p_state, c->p_state + 16, c->h_state.begin());
+  return NIMBLE_OK;
+}
+
+int ensure_host_out(nimble_ctx *c, uint64_t cap) {
+  if (c->hout.cap >= cap) return NIMBLE_OK;
+  // a kernel of an earlier call may still be writing the old block: wait before it goes away
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->hout.base) (void)hipHostFree(c->hout.base);
+  c->hout = nimble_ctx::HostOut();
+  void *p = nullptr;
+  if (hipHostMalloc(&p, cap * 24, hipHostMallocDefault) != hipSuccess)
+    return fail(NIMBLE_E_NOMEM, "page-locked result buffer");
+  c->hout.base = p;
+  c->hout.cap = cap;
+  c->hout.cnt = static_cast<uint64_t *>(p);
+  c->hout.c1 = reinterpret_cast<uint32_t *>(c->hout.cnt + cap);
+  c->hout.c2 = c->hout.c1 + cap;
+  c->hout.seg = c->hout.c2 + cap;
+  c->hout.rep = c->hout.seg + cap;
   return NIMBLE_OK;
 }
 
 // histogram compaction into the context's output arrays (entry count lands in state[11])
 int enqueue_compact(nimble_ctx *c) {
   const uint64_t slots = c->hist_slots;
+  c->out_pinned = slots <= (1ULL << 22);  // 24 B per slot page-locked; larger tables go through device arrays
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, c->stream));
+  if (c->out_pinned) {
+    int rc = ensure_host_out(c, slots);
+    if (rc) return rc;
+    launch_hist_compact(c->stream, c->cb, c->hout.c1, c->hout.c2, c->hout.cnt, slots, c->hout.seg, c->hout.rep);
+    return NIMBLE_OK;
+  }
   int rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_c2.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_cnt.ensure(slots * 8, &c->bytes);
   if (!rc) rc = c->b_out_seg.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_rep.ensure(slots * 4, &c->bytes);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, c->stream));
   launch_hist_compact(c->stream, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(),
                       c->b_out_cnt.as<uint64_t>(), slots, c->b_out_seg.as<uint32_t>(), c->b_out_rep.as<uint32_t>());
   return NIMBLE_OK;
@@ -494,12 +531,20 @@ int finish_call(nimble_ctx *c) {
     if (ne) {
       std::vector<uint32_t> a(ne), b(ne), sg(ne), rp(ne);
       std::vector<uint64_t> k(ne);
-      HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(hipMemcpyAsync(sg.data(), c->b_out_seg.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(hipMemcpyAsync(rp.data(), c->b_out_rep.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(hipStreamSynchronize(c->copy_stream));
+      if (c->out_pinned) {  // written by k_hist_compact into page-locked memory; fetch_state waited for it
+        std::copy(c->hout.c1, c->hout.c1 + ne, a.begin());
+        std::copy(c->hout.c2, c->hout.c2 + ne, b.begin());
+        std::copy(c->hout.cnt, c->hout.cnt + ne, k.begin());
+        std::copy(c->hout.seg, c->hout.seg + ne, sg.begin());
+        std::copy(c->hout.rep, c->hout.rep + ne, rp.begin());
+      } else {
+        HIPCHK(hipMemcpyAsync(a.data(), c->b_out_c1.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipMemcpyAsync(b.data(), c->b_out_c2.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipMemcpyAsync(k.data(), c->b_out_cnt.p, ne * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipMemcpyAsync(sg.data(), c->b_out_seg.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipMemcpyAsync(rp.data(), c->b_out_rep.p, ne * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+      }
       // order by (segment, c1, c2): LSD radix sort of the entry indices, 16 bits per pass, skipping constant digits
       std::vector<uint32_t> idx(ne), tmp(ne);
       for (uint64_t i = 0; i < ne; ++i) idx[i] = (uint32_t)i;

@@ -1465,6 +1465,11 @@ __global__ void k_count_verdicts(nimble_align_params p, CallBuffers cb, const ui
   cb.counted[i] = counted;
 }
 
+// the 16 state words of a call, to page-locked host memory (read by the host after the call's last event)
+__global__ void k_publish_state(const uint64_t *__restrict__ state, uint64_t *__restrict__ host) {
+  if (threadIdx.x < 16) host[threadIdx.x] = state[threadIdx.x];
+}
+
 __global__ void k_fill_u64(uint64_t *p, uint64_t v, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1596,6 +1601,9 @@ void launch_count_verdicts(hipStream_t s, const nimble_align_params &p, const Ca
 void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb) {
   if (cb.n == 0) return;
   hipLaunchKernelGGL(k_records_unpack, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, rec, cb);
+}
+void launch_publish_state(hipStream_t s, const uint64_t *state, uint64_t *host) {
+  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, s, state, host);
 }
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n) {
   if (n == 0) return;
