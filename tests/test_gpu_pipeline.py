@@ -484,8 +484,8 @@ def test_sharded_pipeline_single_rank_rccl(synth_lib, tmp_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("paired", [False, True])
-def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
+@pytest.mark.parametrize("paired,L", [(False, 150), (True, 150), (False, 900)])
+def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired, L):
     # align-where-the-reads-are (nimble_ctx_defer_dedup ... nimble_count_verdicts) with three ranks played by the three
     # call slots of one library and the exchange done by slicing: the shares add up to the direct call over the union,
     # the per-read records are those of a plain local call, and exactly one copy per counted key carries `counted`
@@ -501,7 +501,12 @@ def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
             a, b = synth.make_reads(seqs, n, paired=True, seed=900 + r)
         else:
             a, b = synth.make_reads(seqs, n, seed=900 + r), None
-        reads.append([a.copy(), None if b is None else b.copy()])
+        if L != 150:
+            # long reads (the 150-base read six times over): record rows too wide for the LDS-staged scatter and
+            # owner-side dedup, which fall back to their direct forms
+            a = np.tile(a[:4000], (1, L // 150))
+            assert a.shape[1] == L
+        reads.append([np.ascontiguousarray(a), None if b is None else b.copy()])
     rng = np.random.default_rng(3)
     for _ in range(3000):   # copies across and inside ranks
         x, y = rng.integers(0, world, size=2)
@@ -510,21 +515,21 @@ def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
         if paired:
             reads[y][1][j] = reads[x][1][i]
     u1 = np.concatenate([x[0] for x in reads])
-    o = synth.fixed_offsets(u1.shape[0], 150)
+    o = synth.fixed_offsets(u1.shape[0], L)
     if paired:
         u2 = np.concatenate([x[1] for x in reads])
         direct = lib.score_call(u1.reshape(-1), o, u2.reshape(-1), o)
     else:
-        direct = lib.score_call(u1.reshape(-1), None, n=u1.shape[0], fixed_len=150)
+        direct = lib.score_call(u1.reshape(-1), None, n=u1.shape[0], fixed_len=L)
     # what a plain local call says about every read
     plain = []
     for r in range(world):
         a, b = reads[r]
-        lib.score_call(a.reshape(-1), None, None if b is None else b.reshape(-1), None, n=a.shape[0], fixed_len=150)
+        lib.score_call(a.reshape(-1), None, None if b is None else b.reshape(-1), None, n=a.shape[0], fixed_len=L)
         c = lib.device_context()
         c.n = a.shape[0]
         plain.append([c.read_records(m) for m in range(2 if paired else 1)])
-    kw = nim.key_words(150, paired)
+    kw = nim.key_words(L, paired)
     dev, rec, perm, counts = [], [], [], []
     for r in range(world):
         a, b = reads[r]
@@ -537,7 +542,7 @@ def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
         perm.append(torch.empty((n,), dtype=torch.int32, device="cuda:0"))
         ctx = lib.device_context(slots[r])
         ctx.defer_dedup(world, rec[r], perm[r])
-        lib.score_call_begin(slots[r], d1, None, d2, None, n=n, fixed_len=150, mem=nim.MEM_DEVICE)
+        lib.score_call_begin(slots[r], d1, None, d2, None, n=n, fixed_len=L, mem=nim.MEM_DEVICE)
         counts.append(ctx.route_counts(world))
         assert sum(counts[r]) == n
     # the getters refuse to run before the verdicts are in
@@ -580,7 +585,7 @@ def test_deferred_dedup_form_through_the_c_abi(synth_lib, paired):
     ctx = lib.device_context(0)
     ctx.defer_dedup(world, rec[0], perm[0])
     a = reads[0][0]
-    oo = synth.fixed_offsets(a.shape[0], 150)
+    oo = synth.fixed_offsets(a.shape[0], L)
     with pytest.raises(nim.Panic):
         lib.score_call(a.reshape(-1), oo, a.reshape(-1), oo)
-    assert lib.score_call(a.reshape(-1), None, n=a.shape[0], fixed_len=150)   # disarmed again: a plain call works
+    assert lib.score_call(a.reshape(-1), None, n=a.shape[0], fixed_len=L)   # disarmed again: a plain call works
