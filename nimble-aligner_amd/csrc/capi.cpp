@@ -913,7 +913,9 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   // spill area of the visited-colour lists: only an index with classes outside the 64-row mask form keeps lists
   const uint32_t ws_rows = (!c->ix->dev.all_local && max_len > align_lds_cols()) ? max_len - align_lds_cols() : 0;
   need(c->b_ws, std::max<size_t>((size_t)ws_rows * align_ws_lanes() * 4, 16));
-  const uint64_t dslots = std::max<uint64_t>(n + n / 2, 1024);  // load factor <= 2/3 even if every read is kept
+  // load factor <= 2/3 even if every read is kept (NIMBLE_DEDUP_SLOTS_PCT: slots per 100 reads)
+  static const uint64_t slots_pct = std::min<uint64_t>(std::max<uint64_t>(env_u64("NIMBLE_DEDUP_SLOTS_PCT", 150), 110), 400);
+  const uint64_t dslots = std::min<uint64_t>(std::max<uint64_t>(n * slots_pct / 100, 1024), 0xFFFFFFF0ULL);
   {
     const void *before = c->b_dedup.p;
     need(c->b_dedup, dslots * 8);
