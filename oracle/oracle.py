@@ -149,7 +149,7 @@ class Reference:
         self.h = handle
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # (module globals are gone at interpreter exit)
             lib().ora_ref_free(self.h)
             self.h = None
 
@@ -263,7 +263,7 @@ class Index:
         self.h = handle
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().ora_index_free(self.h)
             self.h = None
 

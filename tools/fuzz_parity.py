@@ -2,11 +2,15 @@
 """Randomised differential test, GPU product vs CPU oracle (development aid): tools/fuzz_parity.py [iterations] [seed]
 Random small libraries (mutated copies, shared segments, repeats, homopolymers), random alignment settings and
 grouping, random reads (errors, junk, N, lower case, ragged lengths, single-end and paired): the final table and the
-per-read (reason, score, mismatches) must be identical."""
+per-read (reason, score, mismatches) must be identical.  Every third plain case also goes through the multi-GPU forms
+on one GPU -- pack / route / calls off the records of every destination, and (single-end) the deferred-dedup form with
+three ranks played by the three call slots -- whose merged tables must equal the direct call's."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+import torch
+torch.cuda.init()   # before the library touches HIP
 nim = importlib.import_module("nimble-aligner_amd")
 from oracle import oracle as ora
 
@@ -81,6 +85,72 @@ def make_reads(rng, seqs, n, lo, hi):
     if n > 4:   # exact duplicates
         for _ in range(n // 10):
             out[int(rng.integers(0, n))] = out[int(rng.integers(0, n))]
+    return out
+
+
+def merged_rows(parts):
+    acc = {}
+    for rows in parts:
+        for f, c in rows:
+            acc[tuple(f)] = acc.get(tuple(f), 0) + c
+    return sorted([list(k), v] for k, v in acc.items())
+
+
+def split_forms(lib, b1, o1, b2, o2, n, paired, max_len, rng):
+    """The same reads through the multi-GPU forms; returns {form name: merged table}."""
+    import torch
+    out = {}
+    world = int(rng.integers(1, 6))
+    ctx = lib.device_context(2)
+    pt = lib.pack(b1, o1, b2, o2, n=n, max_len=max_len, slot=2)
+    rec, counts = pt.route(ctx, world)
+    parts, lo = [], 0
+    for d in range(world):
+        part = rec[lo:lo + counts[d]].contiguous()
+        lo += counts[d]
+        lib.score_call_records_begin(0, part, pt.max_len, pt.paired)
+        parts.append(lib.score_call_end(0))
+    out["records, world %d" % world] = merged_rows(parts)
+    if not paired:
+        slots, kw = (0, 1, 3), pt.key_words
+        cuts = np.sort(rng.integers(0, n + 1, size=2))
+        bounds = [0, int(cuts[0]), int(cuts[1]), n]
+        rank_rec, rank_perm, rank_counts, keep = [], [], [], []
+        for r in range(3):
+            s, e = bounds[r], bounds[r + 1]
+            bb = np.ascontiguousarray(b1[int(o1[s]):int(o1[e])])
+            oo = (o1[s:e + 1] - o1[s]).astype(np.uint64)
+            if bb.size == 0:
+                bb = np.zeros(1, dtype=np.uint8)
+            keep.append((bb, oo))
+            m = e - s
+            rank_rec.append(torch.empty((max(m, 1), kw + 2), dtype=torch.int64, device="cuda:0"))
+            rank_perm.append(torch.empty((max(m, 1),), dtype=torch.int32, device="cuda:0"))
+            c = lib.device_context(slots[r])
+            c.defer_dedup(3, rank_rec[r], rank_perm[r])
+            lib.score_call_begin(slots[r], bb, oo, None, None, n=m, max_len=max_len)
+            rank_counts.append(c.route_counts(3))
+        starts = [np.concatenate([[0], np.cumsum(c)]).astype(np.int64) for c in rank_counts]
+        back = [[None] * 3 for _ in range(3)]
+        for owner in range(3):
+            pieces = [rank_rec[r][starts[r][owner]:starts[r][owner + 1]] for r in range(3)]
+            got = torch.cat(pieces).contiguous()
+            verdict = torch.zeros((max(int(got.shape[0]), 1),), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.dedup_records(got, kw, verdict)
+            ctx.synchronize()
+            lo = 0
+            for r in range(3):
+                m = int(pieces[r].shape[0])
+                back[r][owner] = verdict[lo:lo + m].clone()
+                lo += m
+        parts = []
+        for r in range(3):
+            mine = torch.cat(back[r] + [torch.zeros(1, dtype=torch.uint8, device="cuda:0")]).contiguous()
+            torch.cuda.synchronize()
+            lib.device_context(slots[r]).count_verdicts(mine)
+            parts.append(lib.score_call_end(slots[r]))
+        out["deferred dedup, 3 ranks"] = merged_rows(parts)
     return out
 
 
@@ -174,6 +244,13 @@ for it in range(ITER):
                           open("gpurun_out/fuzz_fail_%d_%d.json" % (SEED, it), "w"))
                 raise SystemExit("iteration %d: %s of mate %d differs at read %d: got %d exp %d" %
                                  (it, k, m, bad, rec[k][bad], exp.per_read[ek][m][bad]))
+    if it % 3 == 0:
+        max_len = int(max(np.diff(o1.astype(np.int64)).max(), np.diff(o2.astype(np.int64)).max() if paired else 0, 1))
+        for form, rows in split_forms(lib, b1, o1, b2, o2, n, paired, max_len, rng).items():
+            if rows != [[f, c] for f, c in got]:
+                json.dump(dict(lib=obj, strand=strand, r1=[x.decode() for x in r1], r2=None if not paired else [x.decode() for x in r2]),
+                          open("gpurun_out/fuzz_fail_%d_%d.json" % (SEED, it), "w"))
+                raise SystemExit("iteration %d: %s: TABLE MISMATCH\n got %s\n exp %s" % (it, form, rows[:5], got[:5]))
     if it % 25 == 0:
         print("iteration", it, "ok (%d features, %d reads, %s, %d rows) %.0fs" % (len(seqs), n, "PE" if paired else "SE", len(got), time.time() - t0), flush=True)
 print("FUZZ OK:", ITER, "iterations, seed", SEED)
