@@ -23,7 +23,7 @@ HIP_LIB_PATH = os.environ.get("NIMBLE_HIP_LIB") or os.path.join(LIB_DIR, "libnim
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_host.so")
 
 CLASS_NONE = 0xFFFFFFFF
-OPT_COUNTERS, OPT_ALIGN_GRID_PCT = 1, 2
+OPT_COUNTERS, OPT_ALIGN_GRID_PCT, OPT_TAIL_ASIDE = 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 
 REASONS = {

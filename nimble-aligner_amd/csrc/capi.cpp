@@ -84,6 +84,7 @@ struct nimble_index {
   // (GPU_MAX_HW_QUEUES, 4 by default); two streams that share a queue run in order, so every extra stream makes it
   // likelier that somebody else's stream (RCCL's) lands behind the launch stream's persistent kernels.
   hipStream_t copy_stream = nullptr;
+  int n_ctx = 0;  // contexts alive on this index
   DevIndex dev{};
   DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
@@ -136,6 +137,8 @@ struct nimble_ctx {
     uint64_t *cnt = nullptr;
   } hout;
   bool out_pinned = false;  // the last compaction went to hout
+  bool tail_aside = false;  // the last call's dedup / count / compaction ran on the side stream
+  uint32_t tail_aside_grid = 0;  // workgroups of k_dedup there (NIMBLE_OPT_TAIL_ASIDE; 0 = stay on the launch stream)
   // BAM-mode extras (nimble_call_ex)
   DevBuf b_route;  // scratch of nimble_route_records
   // align-where-the-reads-are form (nimble_ctx_defer_dedup): the next call routes its keys and stops before dedup
@@ -298,10 +301,11 @@ int ensure_min_cov(nimble_ctx *c, double percent, uint32_t max_len) {
 }
 
 // ev[6] marks the end of everything enqueued for the call so far; the state words are published to the host first
-int mark_done(nimble_ctx *c) {
-  launch_publish_state(c->stream, c->b_state.as<uint64_t>(), c->p_state);
+int mark_done(nimble_ctx *c, hipStream_t on = nullptr) {
+  hipStream_t s = on ? on : c->stream;
+  launch_publish_state(s, c->b_state.as<uint64_t>(), c->p_state);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev[6], c->stream));
+  HIPCHK(hipEventRecord(c->ev[6], s));
   return NIMBLE_OK;
 }
 
@@ -315,6 +319,7 @@ int ensure_host_out(nimble_ctx *c, uint64_t cap) {
   if (c->hout.cap >= cap) return NIMBLE_OK;
   // a kernel of an earlier call may still be writing the old block: wait before it goes away
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
   if (c->hout.base) (void)hipHostFree(c->hout.base);
   c->hout = nimble_ctx::HostOut();
   void *p = nullptr;
@@ -331,14 +336,15 @@ int ensure_host_out(nimble_ctx *c, uint64_t cap) {
 }
 
 // histogram compaction into the context's output arrays (entry count lands in state[11])
-int enqueue_compact(nimble_ctx *c) {
+int enqueue_compact(nimble_ctx *c, hipStream_t on = nullptr) {
+  hipStream_t st = on ? on : c->stream;
   const uint64_t slots = c->hist_slots;
   c->out_pinned = slots <= (1ULL << 22);  // 24 B per slot page-locked; larger tables go through device arrays
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, c->stream));
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 11, 0, 8, st));
   if (c->out_pinned) {
     int rc = ensure_host_out(c, slots);
     if (rc) return rc;
-    launch_hist_compact(c->stream, c->cb, c->hout.c1, c->hout.c2, c->hout.cnt, slots, c->hout.seg, c->hout.rep);
+    launch_hist_compact(st, c->cb, c->hout.c1, c->hout.c2, c->hout.cnt, slots, c->hout.seg, c->hout.rep);
     return NIMBLE_OK;
   }
   int rc = c->b_out_c1.ensure(slots * 4, &c->bytes);
@@ -347,7 +353,7 @@ int enqueue_compact(nimble_ctx *c) {
   if (!rc) rc = c->b_out_seg.ensure(slots * 4, &c->bytes);
   if (!rc) rc = c->b_out_rep.ensure(slots * 4, &c->bytes);
   if (rc) return rc;
-  launch_hist_compact(c->stream, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(),
+  launch_hist_compact(st, c->cb, c->b_out_c1.as<uint32_t>(), c->b_out_c2.as<uint32_t>(),
                       c->b_out_cnt.as<uint64_t>(), slots, c->b_out_seg.as<uint32_t>(), c->b_out_rep.as<uint32_t>());
   return NIMBLE_OK;
 }
@@ -385,6 +391,10 @@ int enqueue_route(nimble_ctx *c) {
 int enqueue_head(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
+  if (c->tail_aside) {  // the previous call of this context finished on the side stream: its buffers are re-used now
+    HIPCHK(hipStreamWaitEvent(s, c->ev[6], 0));
+    c->tail_aside = false;
+  }
   HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   c->dedup_clean_slots = c->defer.active ? c->dslots : 0;  // a deferred call never touches its own table
@@ -411,15 +421,26 @@ int enqueue_tail(nimble_ctx *c) {
     HIPCHK(hipGetLastError());
     return c->defer.counted ? enqueue_count_verdicts(c) : mark_done(c);
   }
-  launch_dedup(s, c->prm, cb);
-  HIPCHK(hipEventRecord(c->ev[4], s));
-  if (!cb.fuse_count) launch_count(s, cb);
+  // Dedup, count and compaction may run on the index's side stream with a small grid: k_dedup is bound by the
+  // chip's atomic rate, which 64 workgroups reach (tools/probes/atomic_rate_cus.hip), so the next call's pack and
+  // align (another context, this launch stream) get the rest of the machine meanwhile.
+  // Only when the index has a second context (calls in flight): a lone call just pays the hop to the other stream.
+  const uint32_t aside_grid = c->tail_aside_grid;
+  hipStream_t t = s;
+  c->tail_aside = aside_grid != 0 && c->ix->n_ctx > 1 && !c->streaming && c->copy_stream != nullptr;
+  if (c->tail_aside) {
+    t = c->copy_stream;
+    HIPCHK(hipStreamWaitEvent(t, c->ev[3], 0));
+  }
+  launch_dedup(t, c->prm, cb, c->tail_aside ? aside_grid : 0u);
+  HIPCHK(hipEventRecord(c->ev[4], t));
+  if (!cb.fuse_count) launch_count(t, cb);
   c->counted_marked = !cb.fuse_count;
-  HIPCHK(hipEventRecord(c->ev[5], s));
-  int rc = enqueue_compact(c);
+  HIPCHK(hipEventRecord(c->ev[5], t));
+  int rc = enqueue_compact(c, t);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  return mark_done(c);
+  return mark_done(c, t);
 }
 
 // Enqueue the whole launch sequence of one call on the context's stream; nothing here waits for the GPU.
@@ -783,6 +804,8 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
     return fail(NIMBLE_E_HIP, "nimble_ctx_create: side stream / pinned buffers");
   }
   c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 0);
+  c->tail_aside_grid = (uint32_t)std::min<uint64_t>(env_u64("NIMBLE_DEDUP_ASIDE", 1024), 1u << 20);
+  ix->n_ctx++;
   *out = c;
   return NIMBLE_OK;
 }
@@ -791,6 +814,8 @@ void nimble_ctx_free(nimble_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  c->ix->n_ctx--;
   delete c;
 }
 
@@ -805,6 +830,11 @@ int nimble_ctx_set_option(nimble_ctx *c, int option, int64_t value) {
   if (option == NIMBLE_OPT_ALIGN_GRID_PCT) {
     if (value < 10 || value > 100) return fail(NIMBLE_E_INVALID, "NIMBLE_OPT_ALIGN_GRID_PCT: 10..100");
     c->align_grid_pct = (int)value;
+    return NIMBLE_OK;
+  }
+  if (option == NIMBLE_OPT_TAIL_ASIDE) {
+    if (value < 0 || value > (1 << 20)) return fail(NIMBLE_E_INVALID, "NIMBLE_OPT_TAIL_ASIDE: 0..1048576 workgroups");
+    c->tail_aside_grid = (uint32_t)value;
     return NIMBLE_OK;
   }
   return fail(NIMBLE_E_INVALID, "nimble_ctx_set_option: unknown option");

@@ -91,7 +91,7 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                   int want_counters, int grid_pct = 100);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
-void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb);
+void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid = 0);  // 0 = one thread per read
 void launch_count(hipStream_t s, const CallBuffers &cb);
 void launch_hist_compact(hipStream_t s, const CallBuffers &cb, uint32_t *c1, uint32_t *c2, uint64_t *cnt,
                          uint64_t cap, uint32_t *seg = nullptr, uint32_t *rep = nullptr);

@@ -1078,10 +1078,7 @@ __device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t seg, ui
 // ---------------------------------------------------------------------------------------------
 // k_dedup: pair filter + insert of the read key into the call's dedup table (last writer wins)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t n = cb.n;
-  if (i >= n) return;
+__device__ __forceinline__ void dedup_one(const nimble_align_params &p, const CallBuffers &cb, uint64_t i) {
   uint32_t c1 = cb.cls[0][i];
   uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
   cb.counted[i] = 0;
@@ -1127,6 +1124,14 @@ __global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
     pos = pos + 1 == cb.dedup_slots ? 0u : pos + 1;
   }
   cb.slot[i] = (uint32_t)pos;
+}
+
+__global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
+  const uint64_t n = cb.n;
+  // grid-stride: the launch may use a small grid (the kernel is bound by the chip's atomic rate, which 64 workgroups
+  // already reach, and then leaves the other CUs to the next call's kernels)
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dedup_one(p, cb, i);
 }
 
 // k_count: the representative of each key adds one to the (class R1, class R2) histogram.  When k_dedup has
@@ -1547,9 +1552,10 @@ void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &
   if (cb.n == 0) return;
   hipLaunchKernelGGL(k_intern_verify, dim3(blocks_for(cb.n, 256), cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb);
 }
-void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb) {
+void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid) {
   if (cb.n == 0) return;
-  hipLaunchKernelGGL(k_dedup, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, p, cb);
+  const uint32_t full = blocks_for(cb.n, 256);
+  hipLaunchKernelGGL(k_dedup, dim3(grid && grid < full ? grid : full), dim3(256), 0, s, p, cb);
 }
 void launch_count(hipStream_t s, const CallBuffers &cb) {
   if (cb.n == 0) return;
