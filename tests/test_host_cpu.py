@@ -43,6 +43,15 @@ def test_hip_library_exports_every_declared_symbol():
     assert L.nimble_abi_version() == 1
 
 
+def test_integration_binding_lists_every_entry_point():
+    # INTEGRATION.md shows the reference-side binding (the Rust extern block): it has to name every function of the header
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("```")]
+    bound = set(re.findall(r"pub fn (nimble_\w+)\(", block))
+    assert bound == set(declared_functions("nimble_hip.h"))
+
+
 def test_host_library_exports_every_declared_symbol():
     L = nim.host_lib()
     names = declared_functions("nimble_host.h")
