@@ -155,7 +155,7 @@ struct nimble_ctx {
     hipEvent_t ev_route = nullptr;
     uint64_t *p_counts = nullptr;  // pinned, 256 entries
   } defer;
-  DevBuf b_seg, b_alen[2], b_skip[2], b_qual[2], b_trim_ls, b_trim_qp, b_hist_rep;
+  DevBuf b_seg, b_alen[2], b_skip[2], b_qual[2], b_trim_ls, b_trim_qp, b_hist_rep, b_hot;
   double trim_strictness = -1.0;
   uint64_t trim_target = ~0ULL;
   std::vector<uint32_t> h_seg, h_rep;
@@ -188,7 +188,7 @@ struct nimble_ctx {
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
                       &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
                       &b_out_cnt, &b_out_seg, &b_out_rep, &b_seg, &b_alen[0], &b_alen[1], &b_skip[0], &b_skip[1], &b_qual[0],
-                      &b_qual[1], &b_route, &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
+                      &b_qual[1], &b_route, &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_hot, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
                       &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
       b->release();
     if (h2d_stream) {
@@ -398,6 +398,7 @@ int enqueue_head(nimble_ctx *c) {
   HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   c->dedup_clean_slots = c->defer.active ? c->dslots : 0;  // a deferred call never touches its own table
+  if (cb.hot) HIPCHK(hipMemsetAsync(cb.hot, 0, (size_t)HOT_KEYS * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
   if (cb.hist_rep) HIPCHK(hipMemsetAsync(cb.hist_rep, 0, c->hist_slots * 4, s));
@@ -463,6 +464,7 @@ int enqueue_call(nimble_ctx *c) {
 
 int redo_dedup_count(nimble_ctx *c) {
   hipStream_t s = c->stream;
+  if (c->cb.hot) HIPCHK(hipMemsetAsync(c->cb.hot, 0, (size_t)HOT_KEYS * 8, s));
   HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
   HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
@@ -956,6 +958,8 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   need(c->b_hist_keys, c->hist_slots * 8);
   need(c->b_hist_cnt, c->hist_slots * 8);
   need(c->b_state, 16 * 8);
+  static const bool hot_keys = env_u64("NIMBLE_HOT_KEYS", 1) != 0;
+  if (hot_keys) need(c->b_hot, (size_t)HOT_KEYS * 8);
   if (rc != NIMBLE_OK) return rc;
   rc = ensure_plog(c, max_len);
   if (rc != NIMBLE_OK) return rc;
@@ -995,6 +999,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   cb.ws_rows = ws_rows;
   cb.ws_lanes = align_ws_lanes();
   cb.dedup = c->b_dedup.as<uint64_t>();
+  cb.hot = c->b_hot.p ? c->b_hot.as<uint64_t>() : nullptr;
   cb.dedup_slots = (uint32_t)dslots;
   cb.hist_keys = c->b_hist_keys.as<uint64_t>();
   cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();

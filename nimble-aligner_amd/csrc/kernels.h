@@ -11,6 +11,7 @@ namespace nimble {
 constexpr uint32_t CLS_NONE = 0xFFFFFFFFu;     // NIMBLE_CLASS_NONE
 constexpr uint32_t CLS_PENDING = 0xFFFFFFFEu;  // passing alignment whose class awaits interning
 constexpr uint32_t SLOT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t HOT_KEYS = 4096;  // direct-mapped set of duplicated key hashes, per call
 constexpr uint64_t HIST_EMPTY = ~0ULL;
 constexpr uint32_t R_TODO = 255;  // prefilter verdict "go on to the walk"
 
@@ -73,6 +74,7 @@ struct CallBuffers {
   uint32_t ws_rows;
   uint32_t ws_lanes;
   uint64_t *dedup;        // {tag<<32 | read index}, 0 = empty
+  uint64_t *hot;          // may be NULL: HOT_KEYS hashes of keys seen more than once (see dedup_one)
   uint32_t dedup_slots;   // not a power of two: slot = mulhi32(hash >> 32, dedup_slots)
   uint64_t *hist_keys;    // (cls1 << 32 | cls2), HIST_EMPTY = empty
   uint64_t *hist_cnt;

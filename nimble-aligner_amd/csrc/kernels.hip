@@ -1104,9 +1104,23 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
   const uint32_t total = rd_len(cb, 0, i) + (cb.paired ? rd_len(cb, 1, i) : 0u);
   const uint32_t nw = (total + 31u) >> 5;
   uint32_t pos = __umulhi((uint32_t)h, cb.dedup_slots);  // low hash half picks the slot, high half is the tag
+  // A key with very many copies (a dominant transcript, an adapter dimer) would put one atomic per copy on ONE
+  // address, and same-address atomics run at ~90 M/s: 5 % copies of one read took 11 ms here.  Every key found a
+  // second time leaves its hash in a small set; a read whose hash is in the set LOOKS at a slot (plain load) before
+  // it touches it with an atomic, and when it finds its key already represented by a later read (reads are taken
+  // from the end of the input backwards, so that is the usual case) it is done without any atomic.  Both kinds of
+  // read share one probe loop, so that a wave with a few such lanes does not run two loops one after the other.
+  const uint64_t hot_slot = h & (uint64_t)(HOT_KEYS - 1);
+  bool look = cb.hot && cb.hot[hot_slot] == h;
   for (;;) {
-    uint64_t cur = atomicCAS((unsigned long long *)&cb.dedup[pos], 0ULL, (unsigned long long)mine);
+    uint64_t cur;
+    if (look) cur = cb.dedup[pos];   // an ordinary cached load; a stale value only costs an atomic further down
+    else cur = atomicCAS((unsigned long long *)&cb.dedup[pos], 0ULL, (unsigned long long)mine);
     if (cur == 0) {
+      if (look) {  // empty as far as this CU can see: claim it atomically
+        look = false;
+        continue;
+      }
       // first copy of this key.  When the classes are a function of the key alone (single-end, or mates of one
       // fixed length) any copy may stand for the key in the histogram, so count it here and skip k_count.
       if (cb.fuse_count) hist_add(cb, seg, c1, c2, (uint32_t)i);
@@ -1114,10 +1128,13 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
     }
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t j = (uint32_t)cur;
-      bool same = (rd_len(cb, 0, j) + (cb.paired ? rd_len(cb, 1, j) : 0u)) == total && (!cb.seg || cb.seg[j] == seg);
-      for (uint32_t w = 0; same && w < nw; ++w) same = rd_key(cb, w, i) == rd_key(cb, w, j);
-      if (same) {
-        atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
+      // all words at once (no early exit): the loads go out back to back, one latency instead of one per word
+      uint64_t diff = (uint64_t)((rd_len(cb, 0, j) + (cb.paired ? rd_len(cb, 1, j) : 0u)) ^ total);
+      if (cb.seg) diff |= (uint64_t)(cb.seg[j] ^ seg);
+      for (uint32_t w = 0; w < nw; ++w) diff |= rd_key(cb, w, i) ^ rd_key(cb, w, j);
+      if (diff == 0) {
+        if (cb.hot && !look) cb.hot[hot_slot] = h;
+        if (j < i) atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
         break;
       }
     }
@@ -1126,12 +1143,15 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
   cb.slot[i] = (uint32_t)pos;
 }
 
-__global__ void k_dedup(nimble_align_params p, CallBuffers cb) {
+__global__ void k_dedup(nimble_align_params p, CallBuffers cb, uint64_t g_begin, uint64_t g_end) {
   const uint64_t n = cb.n;
   // grid-stride: the launch may use a small grid (the kernel is bound by the chip's atomic rate, which 64 workgroups
   // already reach, and then leaves the other CUs to the next call's kernels)
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    dedup_one(p, cb, i);
+  // from the last read backwards: the representative of a key is its LAST copy (score_map.insert overwrites,
+  // src/align.rs:685), so the copies that come later in this order find a slot that already holds a larger index
+  for (uint64_t g = g_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g_end;
+       g += (uint64_t)gridDim.x * blockDim.x)
+    dedup_one(p, cb, n - 1 - g);
 }
 
 // k_count: the representative of each key adds one to the (class R1, class R2) histogram.  When k_dedup has
@@ -1554,8 +1574,14 @@ void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &
 }
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid) {
   if (cb.n == 0) return;
-  const uint32_t full = blocks_for(cb.n, 256);
-  hipLaunchKernelGGL(k_dedup, dim3(grid && grid < full ? grid : full), dim3(256), 0, s, p, cb);
+  // A small first launch over the last reads fills the hot-key set (dedup_one) before the half million threads of
+  // the main launch start together: otherwise every copy of a dominant key in that first wave of threads still
+  // goes to its slot with atomics (5 % copies of one read: 2.5 ms; with the sample ahead: see DESIGN.md).
+  const uint64_t sample = cb.hot && cb.n > (1u << 18) ? (1u << 14) : 0;
+  if (sample)
+    hipLaunchKernelGGL(k_dedup, dim3(blocks_for(sample, 256)), dim3(256), 0, s, p, cb, (uint64_t)0, sample);
+  const uint32_t full = blocks_for(cb.n - sample, 256);
+  hipLaunchKernelGGL(k_dedup, dim3(grid && grid < full ? grid : full), dim3(256), 0, s, p, cb, sample, cb.n);
 }
 void launch_count(hipStream_t s, const CallBuffers &cb) {
   if (cb.n == 0) return;

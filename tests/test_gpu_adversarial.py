@@ -121,3 +121,26 @@ def test_one_key_repeated_and_all_filtered():
     short = np.tile(one[:39], (1000, 1))                              # everything ShortRead
     res = case.check(short.reshape(-1), synth.fixed_offsets(1000, 39))
     assert (res.per_read["reason"][0] == 8).all()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_dominant_keys_among_ordinary_reads(paired):
+    # a few keys with very many copies (a dominant transcript, an adapter dimer) among ordinary reads: the dedup takes
+    # its look-before-atomic path for them (k_dedup: hot-key set, sample launch over the last reads first); table,
+    # per-read records and the representative of every key (its LAST copy) must still be the oracle's
+    names, seqs = synth.make_library(40)
+    case = Case(names, seqs, make_cfg())
+    n = 300_000                                                        # above the size that enables the sample launch
+    rng = np.random.default_rng(77)
+    if paired:
+        r1, r2 = synth.make_reads(seqs, n, paired=True, seed=78)
+    else:
+        r1, r2 = synth.make_reads(seqs, n, seed=78), None
+    for share, src in ((0.2, 11), (0.05, 222), (0.01, 3333), (0.001, 44444)):
+        idx = rng.choice(n, size=int(n * share), replace=False)
+        r1[idx] = r1[src]
+        if paired:
+            r2[idx] = r2[src]
+    o = synth.fixed_offsets(n, 150)
+    res = case.check(r1.reshape(-1), o, None if r2 is None else r2.reshape(-1), None if r2 is None else o)
+    assert res.counters["unique_keys"] < 0.8 * n
