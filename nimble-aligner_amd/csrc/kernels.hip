@@ -1078,7 +1078,20 @@ __device__ __forceinline__ void hist_add(const CallBuffers &cb, uint32_t seg, ui
 // ---------------------------------------------------------------------------------------------
 // k_dedup: pair filter + insert of the read key into the call's dedup table (last writer wins)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dedup_one(const nimble_align_params &p, const CallBuffers &cb, uint64_t i) {
+// Per-block LDS cache of dominant keys (see dedup_one): hash, key words, the slot of the key and an index known to
+// represent it.  Entries are claimed once (state 0 -> 1 -> 2) and never replaced, so a reader never sees a mix of two.
+constexpr uint32_t HC_ENTRIES = 64, HC_WORDS = 10;
+struct HotEntry {
+  uint32_t state, j, pos, total;
+  uint64_t h;
+  uint32_t seg, pad;
+  uint64_t key[HC_WORDS];
+};
+
+// mode: 0 = plain, 1 = the sample launch (plain, but duplicates are counted and leave their hash in the set),
+//       2 = the input has dominant keys (the sample found duplicates): look before the atomic, LDS cache
+__device__ __forceinline__ void dedup_one(const nimble_align_params &p, const CallBuffers &cb, uint64_t i,
+                                          HotEntry *hc, int mode) {
   uint32_t c1 = cb.cls[0][i];
   uint32_t c2 = cb.paired ? cb.cls[1][i] : CLS_NONE;
   cb.counted[i] = 0;
@@ -1111,7 +1124,20 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
   // from the end of the input backwards, so that is the usual case) it is done without any atomic.  Both kinds of
   // read share one probe loop, so that a wave with a few such lanes does not run two loops one after the other.
   const uint64_t hot_slot = h & (uint64_t)(HOT_KEYS - 1);
-  bool look = cb.hot && cb.hot[hot_slot] == h;
+  // ... and what such a read needs to know sits in LDS once a lane of this block has been through memory for it: the
+  // loads of half a million copies otherwise queue at the ONE L2 channel that holds the set entry, the slot and the
+  // representative (~4 ns each: 5 % copies of one read still cost 2 ms with the atomics out of the way).  Every read
+  // looks there first (one LDS read), before the set in global memory.
+  volatile HotEntry *he = hc ? hc + (h & (uint64_t)(HC_ENTRIES - 1)) : nullptr;
+  if (he && nw <= HC_WORDS && he->state == 2u && he->h == h && he->total == total && he->seg == seg && he->j > i) {
+    uint64_t diff = 0;
+    for (uint32_t w = 0; w < nw; ++w) diff |= rd_key(cb, w, i) ^ he->key[w];
+    if (diff == 0) {
+      cb.slot[i] = he->pos;
+      return;
+    }
+  }
+  bool look = mode == 2 && cb.hot[hot_slot] == h;
   for (;;) {
     uint64_t cur;
     if (look) cur = cb.dedup[pos];   // an ordinary cached load; a stale value only costs an atomic further down
@@ -1133,8 +1159,19 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
       if (cb.seg) diff |= (uint64_t)(cb.seg[j] ^ seg);
       for (uint32_t w = 0; w < nw; ++w) diff |= rd_key(cb, w, i) ^ rd_key(cb, w, j);
       if (diff == 0) {
-        if (cb.hot && !look) cb.hot[hot_slot] = h;
+        if (mode != 0 && !look) cb.hot[hot_slot] = h;
+        if (mode == 1) atomicAdd((unsigned long long *)&cb.state[13], 1ULL);
         if (j < i) atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
+        else if (look && he && nw <= HC_WORDS && atomicCAS((uint32_t *)&he->state, 0u, 1u) == 0u) {
+          he->h = h;
+          he->total = total;
+          he->seg = seg;
+          he->j = (uint32_t)j;
+          he->pos = pos;
+          for (uint32_t w = 0; w < nw; ++w) he->key[w] = rd_key(cb, w, i);
+          __threadfence_block();
+          he->state = 2u;
+        }
         break;
       }
     }
@@ -1143,15 +1180,24 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
   cb.slot[i] = (uint32_t)pos;
 }
 
-__global__ void k_dedup(nimble_align_params p, CallBuffers cb, uint64_t g_begin, uint64_t g_end) {
+__global__ __launch_bounds__(256) void k_dedup(nimble_align_params p, CallBuffers cb, uint64_t g_begin,
+                                               uint64_t g_end) {
+  __shared__ HotEntry s_hot[HC_ENTRIES];
+  for (uint32_t e = threadIdx.x; e < HC_ENTRIES; e += blockDim.x) s_hot[e].state = 0u;
+  __syncthreads();
   const uint64_t n = cb.n;
+  // The sample launch (the last reads, g_begin == 0 of a split launch) counts the duplicates it meets; only when it
+  // met some does the main launch pay for the look-before-atomic machinery.
+  const bool is_sample = cb.hot && g_begin == 0 && g_end < n;
+  const int mode = !cb.hot ? 0 : is_sample ? 1 : (g_begin != 0 && cb.state[13] >= 4 ? 2 : 0);
+  HotEntry *hc = mode == 2 ? s_hot : nullptr;
   // grid-stride: the launch may use a small grid (the kernel is bound by the chip's atomic rate, which 64 workgroups
   // already reach, and then leaves the other CUs to the next call's kernels)
   // from the last read backwards: the representative of a key is its LAST copy (score_map.insert overwrites,
   // src/align.rs:685), so the copies that come later in this order find a slot that already holds a larger index
   for (uint64_t g = g_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g_end;
        g += (uint64_t)gridDim.x * blockDim.x)
-    dedup_one(p, cb, n - 1 - g);
+    dedup_one(p, cb, n - 1 - g, hc, mode);
 }
 
 // k_count: the representative of each key adds one to the (class R1, class R2) histogram.  When k_dedup has
@@ -1577,11 +1623,17 @@ void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers
   // A small first launch over the last reads fills the hot-key set (dedup_one) before the half million threads of
   // the main launch start together: otherwise every copy of a dominant key in that first wave of threads still
   // goes to its slot with atomics (5 % copies of one read: 2.5 ms; with the sample ahead: see DESIGN.md).
-  const uint64_t sample = cb.hot && cb.n > (1u << 18) ? (1u << 14) : 0;
+  static const uint64_t min_reads = getenv("NIMBLE_HOT_MIN_READS") ? strtoull(getenv("NIMBLE_HOT_MIN_READS"), nullptr, 10)
+                                                                     : (1ull << 18);
+  const uint64_t sample = cb.hot && cb.n > min_reads && cb.n >= 8 ? (cb.n / 4 < (1u << 14) ? cb.n / 4 : (1u << 14)) : 0;
   if (sample)
     hipLaunchKernelGGL(k_dedup, dim3(blocks_for(sample, 256)), dim3(256), 0, s, p, cb, (uint64_t)0, sample);
+  // at most 4096 workgroups striding over the reads: what a block learns about a dominant key serves all its later
+  // tiles (2048: dominant keys cheaper still, but 0.63 instead of 0.53 ms without any; the full grid: 0.51 ms)
   const uint32_t full = blocks_for(cb.n - sample, 256);
-  hipLaunchKernelGGL(k_dedup, dim3(grid && grid < full ? grid : full), dim3(256), 0, s, p, cb, sample, cb.n);
+  static const uint32_t persistent = (uint32_t)(getenv("NIMBLE_DEDUP_GRID") ? atoi(getenv("NIMBLE_DEDUP_GRID")) : 4096);
+  const uint32_t cap = grid ? grid : persistent;
+  hipLaunchKernelGGL(k_dedup, dim3(cap < full ? cap : full), dim3(256), 0, s, p, cb, sample, cb.n);
 }
 void launch_count(hipStream_t s, const CallBuffers &cb) {
   if (cb.n == 0) return;
