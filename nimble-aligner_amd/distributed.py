@@ -252,6 +252,17 @@ def sharded_step(lib, r1, r2, n, fixed_len, device, reducer, group=None):
     return out
 
 
+def _rows_buffer(bufs, tag, rows, width, device, dtype=torch.int64):
+    """A [rows, width] view of a re-used buffer with head-room: batches differ a little in how many records a rank
+    receives, and an allocation inside the pipeline waits for the call in flight (and frees what a kernel may still
+    read) -- so the buffer only ever grows, by a quarter at a time."""
+    t = bufs.get(tag)
+    if t is None or t.shape[0] < rows or t.shape[1] != width:
+        t = torch.empty((max(int(rows * 1.25) + 1024, 1), width), dtype=dtype, device=device)
+        bufs[tag] = t
+    return t[:rows]
+
+
 class ShardedPipeline:
     """The multi-GPU step, software-pipelined over successive batches.  For batch b:
          P(b) pack + route            launch stream (utility context)
@@ -350,7 +361,8 @@ class ShardedPipeline:
         counts = self.util.route_counts(self.world)     # the host waits for P(b) only
         t4 = time.perf_counter()
         got = exchange_routed(rec, counts, self.group,     # X(b) while C(b-1) runs; nobody on the host waits for it
-                              alloc=lambda rows: self._tensor(("got", b % 3), (rows, pt.key_words + 2)),
+                              alloc=lambda rows: _rows_buffer(self._bufs, ("got", b % 3), rows, pt.key_words + 2,
+                                                              self.device),
                               staging=self.reducer.staging)
         ev = torch.cuda.Event()
         ev.record()
@@ -460,11 +472,12 @@ class LocalAlignPipeline:
         counts = ctx.route_counts(self.world)                                    # the host waits for P(b) only
         t2 = time.perf_counter()
         got, recv_counts = exchange_routed(rec[:n], counts, self.group, staging=self.reducer.staging, with_counts=True,
-                                           alloc=lambda rows: self._tensor(("got", k), (max(rows, 1), kw + 2))[:rows])
+                                           alloc=lambda rows: _rows_buffer(self._bufs, ("got", k), rows, kw + 2,
+                                                                           self.device))
         x1 = torch.cuda.Event()
         x1.record()                                                              # X1(b), beside A(b)
         self.launch.wait_event(x1)
-        owner = self._tensor(("owner", k), (max(int(got.shape[0]), 1),), torch.uint8)[:int(got.shape[0])]
+        owner = _rows_buffer(self._bufs, ("owner", k), int(got.shape[0]), 1, self.device, torch.uint8)[:, 0]
         self.util.dedup_records(got, kw, owner)                                  # D(b)
         d = torch.cuda.Event()
         d.record(self.launch)
