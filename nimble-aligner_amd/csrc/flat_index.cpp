@@ -350,7 +350,24 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   for (size_t c = 0; c < out.n_colours; ++c) {
     uint32_t o = out.col_off[c], l = out.col_off[c + 1] - o;
     make_class_desc(out.col_ids.data() + o, l, &out.cls_desc[c * 4]);
-    if (!(out.cls_desc[c * 4] & CLS_MASK_FLAG)) out.all_classes_local = false;
+    if (!(out.cls_desc[c * 4] & CLS_MASK_FLAG)) {
+      out.all_classes_local = false;
+      // a class wider than the 64-row mask form gets a bitmap over the rows it spans (allele families: the rows of
+      // a gene are neighbours, so a class of 100 alleles spans a few hundred rows): the device intersects such
+      // classes word by word instead of searching id lists
+      const uint32_t first = out.col_ids[o], span = out.col_ids[o + l - 1] - first + 1u;
+      if (l && span <= CLS_BITMAP_MAX_ROWS && out.cls_bits.size() + (span + 63u) / 64u < 0xFFFFFFFEull) {
+        const size_t at = out.cls_bits.size();
+        out.cls_bits.resize(at + (span + 63u) / 64u, 0ULL);
+        for (uint32_t t = 0; t < l; ++t) {
+          const uint32_t r = out.col_ids[o + t] - first;
+          out.cls_bits[at + (r >> 6)] |= 1ULL << (r & 63u);
+        }
+        out.cls_desc[c * 4 + 1] = first;
+        out.cls_desc[c * 4 + 2] = span;
+        out.cls_desc[c * 4 + 3] = (uint32_t)at + 1u;
+      }
+    }
   }
   for (size_t nd = 0; nd < n_nodes; ++nd) {
     const uint32_t c = out.node_rec[nd * 16 + 1];

@@ -18,7 +18,8 @@ constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
 constexpr uint32_t NODE_INLINE_BASES = 64;
 constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
-constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;  // set in the descriptor's len word when the mask form is valid
+constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;
+constexpr uint32_t CLS_BITMAP_MAX_ROWS = 1u << 16;  // widest span a static class gets a row bitmap for (8 KiB)  // set in the descriptor's len word when the mask form is valid
 
 // shared by host build and device kernels ----------------------------------------------------
 #if defined(__HIPCC__)
@@ -148,6 +149,7 @@ struct FlatIndex {
   // intersection of visited colours is one 16-byte load per colour plus shift/AND.  Classes that span 64
   // rows or more keep len without the flag and are intersected through the CSR ids.
   std::vector<uint32_t> cls_desc;    // 4 x u32 per class
+  std::vector<uint64_t> cls_bits;    // row bitmaps of the classes wider than the mask form (cls_desc words 1..3)
   bool all_classes_local = true;     // every static class has the mask form
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };

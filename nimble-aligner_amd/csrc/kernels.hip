@@ -674,42 +674,101 @@ struct IRes {
   uint32_t count;
   uint64_t hash;
 };
+// 64 rows of class d starting at row `row0`, as a bit mask.  Mask-form classes carry their bits in the descriptor;
+// a wider static class has a span bitmap in ix.cls_bits (descriptor: y = first row, z = rows spanned, w = word
+// offset + 1), built with the index.
+__device__ __forceinline__ uint64_t class_rows64(const uint4 &d, const uint64_t *__restrict__ cls_bits, uint32_t row0) {
+  if (desc_is_mask(d)) return mask_in_window(d, row0);
+  if (row0 + 64u <= d.y || row0 >= d.y + d.z) return 0ULL;
+  const uint64_t *__restrict__ w = cls_bits + (d.w - 1u);
+  const uint32_t n_words = (d.z + 63u) >> 6;
+  if (row0 < d.y) return w[0] << (d.y - row0);  // the window starts before the class does (delta < 64 here)
+  const uint32_t off = row0 - d.y, q = off >> 6, sh = off & 63u;
+  uint64_t v = w[q] >> sh;
+  if (sh && q + 1u < n_words) v |= w[q + 1u] << (64u - sh);
+  return v;
+}
+
 __device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint32_t *cls_off, const uint32_t *cls_ids,
-                                               const uint32_t *lc, const uint32_t *ws, uint32_t ws_lanes,
-                                               uint32_t n_cols, uint32_t best, uint32_t bl, uint32_t *out) {
-  const uint32_t *bids = cls_ids + cls_off[best];
+                                               const uint64_t *cls_bits, const uint32_t *lc, const uint32_t *ws,
+                                               uint32_t ws_lanes, uint32_t n_cols, uint32_t best, uint32_t bl,
+                                               uint32_t *out) {
   uint32_t count = 0, first_id = 0, last_id = 0;
   uint64_t gmask = 0;
   uint64_t h = class_hash_init();
-  for (uint32_t t = 0; t < bl; ++t) {
-    const uint32_t id = bids[t];
-    bool ok = true;
-    for (uint32_t j = 0; j < n_cols && ok; ++j) {
-      const uint32_t c = j < LDS_COLS ? lc[j * ALIGN_BLOCK] : ws[(uint64_t)(j - LDS_COLS) * ws_lanes];
-      if (c == best) continue;
-      const uint4 d = cls_desc[c];
-      if (desc_is_mask(d)) {
-        const uint32_t off = id - d.y;
-        ok = id >= d.y && off < 64u && ((desc_mask(d) >> off) & 1ULL);
-      } else {
-        const uint32_t len = desc_len(d);
-        const uint32_t *__restrict__ ids = cls_ids + cls_off[c];
-        uint32_t lo = 0, hi = len;
-        while (lo < hi) {
-          uint32_t mid = (lo + hi) >> 1;
-          if (ids[mid] < id) lo = mid + 1;
-          else hi = mid;
-        }
-        ok = lo < len && ids[lo] == id;
-      }
+  // Bitmap form: when every visited class is a 64-row mask or has a span bitmap, the intersection is an AND of
+  // 64-row words over the rows all of them cover -- a few loads per class and word instead of a binary search per
+  // row of the smallest class and visited class (allele families of 100 rows: 384 -> see DESIGN.md).
+  bool bitmaps = true;
+  uint32_t lo = 0, hi = 0xFFFFFFFFu;  // rows every class could contain: [lo, hi]
+  for (uint32_t j = 0; j < n_cols; ++j) {
+    const uint32_t c = j < LDS_COLS ? lc[j * ALIGN_BLOCK] : ws[(uint64_t)(j - LDS_COLS) * ws_lanes];
+    const uint4 d = cls_desc[c];
+    uint32_t f, l;
+    if (desc_is_mask(d)) {
+      const uint64_t m = desc_mask(d);
+      f = d.y;
+      l = d.y + 63u - (uint32_t)__clzll((long long)m);
+    } else if (d.w != 0u) {
+      f = d.y;
+      l = d.y + d.z - 1u;
+    } else {
+      bitmaps = false;
+      break;
     }
-    if (ok) {
-      if (out) out[count] = id;
-      h = class_hash_step(h, id);
-      if (count == 0) first_id = id;
-      last_id = id;
-      if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
-      ++count;
+    lo = f > lo ? f : lo;
+    hi = l < hi ? l : hi;
+  }
+  if (bitmaps) {
+    for (uint32_t row0 = lo; lo <= hi && row0 <= hi; row0 += 64u) {
+      uint64_t acc = hi - row0 >= 63u ? ~0ULL : ((1ULL << (hi - row0 + 1u)) - 1ULL);
+      for (uint32_t j = 0; j < n_cols && acc; ++j) {
+        const uint32_t c = j < LDS_COLS ? lc[j * ALIGN_BLOCK] : ws[(uint64_t)(j - LDS_COLS) * ws_lanes];
+        acc &= class_rows64(cls_desc[c], cls_bits, row0);
+      }
+      for (; acc; acc &= acc - 1) {
+        const uint32_t id = row0 + (uint32_t)__ffsll((long long)acc) - 1u;
+        if (out) out[count] = id;
+        h = class_hash_step(h, id);
+        if (count == 0) first_id = id;
+        last_id = id;
+        if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
+        ++count;
+      }
+      if (row0 > 0xFFFFFFFFu - 64u) break;
+    }
+  } else {
+    const uint32_t *bids = cls_ids + cls_off[best];
+    for (uint32_t t = 0; t < bl; ++t) {
+      const uint32_t id = bids[t];
+      bool ok = true;
+      for (uint32_t j = 0; j < n_cols && ok; ++j) {
+        const uint32_t c = j < LDS_COLS ? lc[j * ALIGN_BLOCK] : ws[(uint64_t)(j - LDS_COLS) * ws_lanes];
+        if (c == best) continue;
+        const uint4 d = cls_desc[c];
+        if (desc_is_mask(d)) {
+          const uint32_t off = id - d.y;
+          ok = id >= d.y && off < 64u && ((desc_mask(d) >> off) & 1ULL);
+        } else {
+          const uint32_t len = desc_len(d);
+          const uint32_t *__restrict__ ids = cls_ids + cls_off[c];
+          uint32_t blo = 0, bhi = len;
+          while (blo < bhi) {
+            uint32_t mid = (blo + bhi) >> 1;
+            if (ids[mid] < id) blo = mid + 1;
+            else bhi = mid;
+          }
+          ok = blo < len && ids[blo] == id;
+        }
+      }
+      if (ok) {
+        if (out) out[count] = id;
+        h = class_hash_step(h, id);
+        if (count == 0) first_id = id;
+        last_id = id;
+        if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
+        ++count;
+      }
     }
   }
   IRes r;
@@ -727,12 +786,13 @@ struct MaskRes {  // the result as base + mask (valid when is_mask), normalised 
   uint32_t base;
   uint64_t mask;
 };
+template <bool WIDE>
 __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &hash, uint32_t *out, MaskRes &mr) {
-  mr.is_mask = ln.all_mask;
+  mr.is_mask = !WIDE || ln.all_mask;
   mr.base = 0;
   mr.mask = 0;
-  if (!ln.all_mask) {
-    const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ln.lc, ln.ws, ln.ws_lanes, ln.n_cols,
+  if (WIDE && !ln.all_mask) {
+    const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ix.cls_bits, ln.lc, ln.ws, ln.ws_lanes, ln.n_cols,
                                      ln.min_col, ln.min_len, out);
     hash = r.hash;
     return r.count;
@@ -758,7 +818,10 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
 #ifndef NIMBLE_ALIGN_WAVES
 #define NIMBLE_ALIGN_WAVES 8
 #endif
-template <bool PAIRED, bool COUNTERS>
+// WIDE: the index has classes wider than the 64-row mask form (ix.all_local == 0): the visited colours are kept and
+// the intersection may go through intersect_general.  The other instantiation carries none of that code -- the
+// out-of-line call alone costs the walk registers around it.
+template <bool PAIRED, bool COUNTERS, bool WIDE>
 __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   constexpr int want_counters = COUNTERS ? 1 : 0;
@@ -780,7 +843,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   ln.acc = 0;
   ln.fbase = ln.min_len = ln.min_col = 0;
   ln.all_mask = true;
-  ln.keep_list = ix.all_local == 0;
+  ln.keep_list = WIDE;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
   constexpr int nm = PAIRED ? 2 : 1;
@@ -896,7 +959,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
             uint32_t count;
             best_col = ln.min_col;
             best_len = ln.min_len;
-            count = finish_class(ix, ln, dhash, nullptr, mres);
+            count = finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
             // `score as f64 / len as f64 >= score_percent` (align.rs:968, filter/align.rs:16) as an exact
             // integer test: min_cov[len] is the smallest score whose IEEE quotient reaches score_percent
             if (p.discard_nonzero_mismatch && mis != 0) {
@@ -951,7 +1014,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
         if (base + ofs + need <= (unsigned long long)cb.scratch_cap) {
           uint64_t hh;
           MaskRes m2;
-          finish_class(ix, ln, hh, cb.scratch + base + ofs, m2);
+          finish_class<WIDE>(ix, ln, hh, cb.scratch + base + ofs, m2);
           cb.dyn_off[m][r] = (uint32_t)base + ofs;
           cb.dyn_len[m][r] = need;
           cb.dyn_hash[m][r] = dhash;
@@ -1016,6 +1079,24 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
       for (uint32_t t = 0; t < len; ++t) ix.cls_ids[off + t] = src[t];
       uint32_t desc[4];
       make_class_desc(src, len, desc);
+      if (!(desc[0] & CLS_MASK_FLAG) && len) {
+        // a wide class gets its row bitmap too (as the static ones have, flat_index.cpp): the align kernel then finds
+        // it again by comparing words instead of sending every read that produces it through these kernels
+        const uint32_t first = src[0], span = src[len - 1] - first + 1u, words = (span + 63u) >> 6;
+        if (span <= CLS_BITMAP_MAX_ROWS) {
+          const uint32_t at = atomicAdd(&ix.dyn_state[3], words);
+          if ((uint64_t)at + words <= ix.bits_cap) {
+            for (uint32_t w = 0; w < words; ++w) ix.cls_bits[at + w] = 0ULL;
+            for (uint32_t t = 0; t < len; ++t) {
+              const uint32_t r = src[t] - first;
+              ix.cls_bits[at + (r >> 6)] |= 1ULL << (r & 63u);
+            }
+            desc[1] = first;
+            desc[2] = span;
+            desc[3] = at + 1u;
+          }
+        }
+      }
       ix.cls_off[id] = off;
       ix.cls_desc[id] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
       ix.intern[pos] = ((uint64_t)tag << 32) | id;
@@ -1584,12 +1665,13 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (lds > 48 * 1024) {  // long reads: opt in to more dynamic LDS than the default limit
-      (void)hipFuncSetAttribute((const void *)k_align<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void *)k_align<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void *)k_align<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void *)k_align<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const void *all[8] = {(const void *)k_align<true, true, true>,   (const void *)k_align<true, true, false>,
+                            (const void *)k_align<true, false, true>,  (const void *)k_align<true, false, false>,
+                            (const void *)k_align<false, true, true>,  (const void *)k_align<false, true, false>,
+                            (const void *)k_align<false, false, true>, (const void *)k_align<false, false, false>};
+      for (const void *f : all) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align<true, true>, ALIGN_BLOCK, lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align<true, true, true>, ALIGN_BLOCK, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 4;
     if (cus < 1) cus = 256;
@@ -1601,13 +1683,16 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   uint64_t resident = (uint64_t)resident_cache[key] * (uint64_t)(grid_pct < 10 ? 10 : (grid_pct > 100 ? 100 : grid_pct)) / 100;
   if (resident < 1) resident = 1;
   uint32_t grid = (uint32_t)(tiles < resident ? tiles : resident);
+  const bool wide = ix.all_local == 0;
+#define NIMBLE_LAUNCH_ALIGN(P, C, W) hipLaunchKernelGGL((k_align<P, C, W>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb)
   if (cb.paired) {
-    if (want_counters) hipLaunchKernelGGL((k_align<true, true>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
-    else hipLaunchKernelGGL((k_align<true, false>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+    if (want_counters) { if (wide) NIMBLE_LAUNCH_ALIGN(true, true, true); else NIMBLE_LAUNCH_ALIGN(true, true, false); }
+    else { if (wide) NIMBLE_LAUNCH_ALIGN(true, false, true); else NIMBLE_LAUNCH_ALIGN(true, false, false); }
   } else {
-    if (want_counters) hipLaunchKernelGGL((k_align<false, true>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
-    else hipLaunchKernelGGL((k_align<false, false>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb);
+    if (want_counters) { if (wide) NIMBLE_LAUNCH_ALIGN(false, true, true); else NIMBLE_LAUNCH_ALIGN(false, true, false); }
+    else { if (wide) NIMBLE_LAUNCH_ALIGN(false, false, true); else NIMBLE_LAUNCH_ALIGN(false, false, false); }
   }
+#undef NIMBLE_LAUNCH_ALIGN
 }
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {

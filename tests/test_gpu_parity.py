@@ -248,6 +248,39 @@ def test_wide_classes_general_intersection_path():
     assert st["dynamic_classes"] > 0  # intersections that are not k-mer colours were interned on the device
 
 
+def test_large_allele_families_bitmap_intersection():
+    """Families of 150 alleles at 1 % divergence (what an immune-gene library looks like): the classes of the shared
+    k-mers span hundreds of neighbouring rows, beyond the 64-row mask form; the device intersects their row bitmaps
+    word by word (intersect_general, bitmap form).  Table, per-read records and class contents against the oracle."""
+    rng = np.random.default_rng(23)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    names, seqs = [], []
+    for fam, size in enumerate((150, 70, 150, 3)):
+        length = int(rng.integers(500, 900))
+        root = rng.integers(0, 4, size=length, dtype=np.uint8)
+        for k in range(size):
+            a = root.copy()
+            if k:
+                m = rng.random(length) < 0.01
+                a[m] = (a[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
+            names.append("G%d*%03d" % (fam, k))
+            seqs.append(acgt[a].tobytes().decode())
+    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=30, max_hits_to_report=400))
+    reads = []
+    for _ in range(8000):
+        f = int(rng.integers(0, len(seqs)))
+        st = int(rng.integers(0, len(seqs[f]) - 150))
+        r = np.frombuffer(seqs[f][st:st + 150].encode(), dtype=np.uint8).copy()
+        if rng.random() < 0.4:
+            r[int(rng.integers(0, 150))] = ord("ACGT"[int(rng.integers(0, 4))])
+        reads.append(r.tobytes())
+    b, o = ora.pack_reads(reads)
+    for nm in (0, 2):
+        case.check(b, o, cfg=case.cfg.copy(num_mismatches=nm))
+    st = case.dindex.stats()
+    assert st["dynamic_classes"] > 0
+
+
 def test_empty_call(synth_case):
     case, _ = synth_case
     b, o = ora.pack_reads([])
