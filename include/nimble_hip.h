@@ -108,7 +108,7 @@ enum {
    * CU keeps room for the kernels of another stream -- a multi-GPU pipeline sets 87 so that RCCL's exchange of the
    * next batch runs beside the align kernel instead of behind it */
   NIMBLE_OPT_ALIGN_GRID_PCT = 2,
-  /* workgroups (0..1048576, default 1024 = NIMBLE_DEDUP_ASIDE) of the dedup kernel when the tail of a call (dedup,
+  /* workgroups (0..1048576, default 1280 = NIMBLE_DEDUP_ASIDE) of the dedup kernel when the tail of a call (dedup,
    * count, compaction) runs on the index's side stream instead of the launch stream.  Used only while the index
    * has more than one context, i.e. calls in flight: the dedup is bound by the chip's atomic rate, not by CUs, so
    * the next call's pack and align start beside it.  0 keeps the tail on the launch stream. */

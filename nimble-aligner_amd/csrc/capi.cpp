@@ -811,7 +811,7 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
     return fail(NIMBLE_E_HIP, "nimble_ctx_create: side stream / pinned buffers");
   }
   c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 0);
-  c->tail_aside_grid = (uint32_t)std::min<uint64_t>(env_u64("NIMBLE_DEDUP_ASIDE", 1024), 1u << 20);
+  c->tail_aside_grid = (uint32_t)std::min<uint64_t>(env_u64("NIMBLE_DEDUP_ASIDE", 1280), 1u << 20);
   ix->n_ctx++;
   *out = c;
   return NIMBLE_OK;
