@@ -29,7 +29,7 @@ head = ("# rocprofv3 --pmc <one group per pass> --kernel-trace -- python3 bench.
         "# FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE tallies 128-B requests at 64 B on gfx950 (double it).\n"
         % bench["config"]["workload"])
 open(os.path.join(dst, rnd + "_pmc_summary.txt"), "w").write(head + summary)
-blk = re.search(r"^k_align<false, false>\n((?:  .*\n)+)", summary, re.M)
+blk = re.search(r"^k_align<false, false(?:, false)?>\n((?:  .*\n)+)", summary, re.M)
 vals = dict(re.findall(r"^\s+(\S+)\s+avg/dispatch\s+(\S+)", blk.group(1), re.M)) if blk else {}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     fetch, write = float(vals["FETCH_SIZE"]) * 1024, float(vals["WRITE_SIZE"]) * 1024
