@@ -670,9 +670,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   std::vector<uint32_t> coff(fi.col_off.begin(), fi.col_off.end() - 1);
   up(ix->b_cls_off, coff, cls_cap);
   up(ix->b_cls_ids, fi.col_ids, ids_cap);
-  // room for the bitmaps of classes interned at run time (NIMBLE_DYN_BITS words; a class of 500 rows takes 8)
-  const uint64_t bits_cap = std::min<uint64_t>(fi.cls_bits.size() + env_u64("NIMBLE_DYN_BITS", 1ULL << 22), 0xFFFFFFF0ULL);
-  up(ix->b_cls_bits, fi.cls_bits, (size_t)bits_cap);
+  up(ix->b_cls_bits, fi.cls_bits, 2);
   // intern table seeded with the static classes, so that an intersection equal to a k-mer colour
   // resolves to that colour's id (class ids are canonical by content)
   const uint64_t islots = pow2_at_least(4 * cls_cap);
@@ -684,7 +682,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
     intern[pos] = ((uint64_t)intern_tag(h) << 32) | (uint32_t)c;
   }
   up(ix->b_intern, intern);
-  std::vector<uint32_t> dyn_state = {(uint32_t)fi.n_colours, (uint32_t)fi.col_ids.size(), 0, (uint32_t)fi.cls_bits.size()};
+  std::vector<uint32_t> dyn_state = {(uint32_t)fi.n_colours, (uint32_t)fi.col_ids.size(), 0, 0};
   up(ix->b_dyn_state, dyn_state);
   if (rc != NIMBLE_OK) {
     delete ix;
@@ -706,7 +704,6 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.cls_off = ix->b_cls_off.as<uint32_t>();
   d.cls_ids = ix->b_cls_ids.as<uint32_t>();
   d.cls_bits = ix->b_cls_bits.as<uint64_t>();
-  d.bits_cap = bits_cap;
   d.n_static = (uint32_t)fi.n_colours;
   d.cls_cap = (uint32_t)cls_cap;
   d.ids_cap = (uint32_t)ids_cap;

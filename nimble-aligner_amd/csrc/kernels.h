@@ -30,15 +30,14 @@ struct DevIndex {
                             //  rows spanned, word offset + 1 into cls_bits (0 = no bitmap)}
   uint32_t *cls_off;        // offset of the class in cls_ids (CSR form, every class has it)
   uint32_t *cls_ids;
-  uint64_t *cls_bits;       // row bitmaps of the classes wider than the mask form (see cls_desc); static ones first
-  uint64_t bits_cap;        // capacity of cls_bits in words
+  const uint64_t *cls_bits; // row bitmaps of the static classes wider than the mask form (see cls_desc)
   uint32_t all_local;       // every static class is in mask form: no colour list is kept during the walk
   uint32_t n_static;
   uint32_t cls_cap;       // capacity in classes
   uint32_t ids_cap;       // capacity of cls_ids
   uint64_t *intern;       // {tag<<32 | class id}, 0 = empty
   uint64_t intern_mask;
-  uint32_t *dyn_state;    // [0]=next class id [1]=next free id slot in cls_ids [2]=overflow flag [3]=next free word in cls_bits
+  uint32_t *dyn_state;    // [0]=next class id [1]=next free id slot in cls_ids [2]=overflow flag
 };
 
 // per-call device arrays (SoA, stride = n; the packed keys have their own stride so that a streamed call can

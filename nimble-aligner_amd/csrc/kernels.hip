@@ -1079,24 +1079,6 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
       for (uint32_t t = 0; t < len; ++t) ix.cls_ids[off + t] = src[t];
       uint32_t desc[4];
       make_class_desc(src, len, desc);
-      if (!(desc[0] & CLS_MASK_FLAG) && len) {
-        // a wide class gets its row bitmap too (as the static ones have, flat_index.cpp): the align kernel then finds
-        // it again by comparing words instead of sending every read that produces it through these kernels
-        const uint32_t first = src[0], span = src[len - 1] - first + 1u, words = (span + 63u) >> 6;
-        if (span <= CLS_BITMAP_MAX_ROWS) {
-          const uint32_t at = atomicAdd(&ix.dyn_state[3], words);
-          if ((uint64_t)at + words <= ix.bits_cap) {
-            for (uint32_t w = 0; w < words; ++w) ix.cls_bits[at + w] = 0ULL;
-            for (uint32_t t = 0; t < len; ++t) {
-              const uint32_t r = src[t] - first;
-              ix.cls_bits[at + (r >> 6)] |= 1ULL << (r & 63u);
-            }
-            desc[1] = first;
-            desc[2] = span;
-            desc[3] = at + 1u;
-          }
-        }
-      }
       ix.cls_off[id] = off;
       ix.cls_desc[id] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
       ix.intern[pos] = ((uint64_t)tag << 32) | id;
