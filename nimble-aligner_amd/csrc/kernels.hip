@@ -1556,12 +1556,20 @@ __global__ void k_dedup_records(const uint64_t *__restrict__ rec, uint64_t n, ui
   const uint64_t mine = ((uint64_t)tag << 32) | (uint32_t)j;
   uint32_t pos = __umulhi((uint32_t)h, slots);
   uint8_t first = 0;
+  bool look = true;  // look before the atomic: the copies of a dominant key must not all CAS its one slot (k_dedup)
   for (;;) {
-    const uint64_t cur = atomicCAS((unsigned long long *)&table[pos], 0ULL, (unsigned long long)mine);
+    uint64_t cur;
+    if (look) cur = table[pos];
+    else cur = atomicCAS((unsigned long long *)&table[pos], 0ULL, (unsigned long long)mine);
     if (cur == 0) {
+      if (look) {
+        look = false;
+        continue;
+      }
       first = 1;
       break;
     }
+    look = true;
     if ((uint32_t)(cur >> 32) == tag) {
       const uint64_t *q = rec + (uint64_t)(uint32_t)cur * rw;
       const uint64_t m2 = q[kw + 1];
