@@ -1050,12 +1050,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
 // class interning: content-addressed table {tag | class id}; claims and verification are split by a
 // kernel boundary so that no lane ever waits on another lane.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
-  if (cb.state[8] == 0) return;  // no class was parked in the scratch pool: nothing is pending (the usual case)
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t n = cb.n;
-  const int m = (int)blockIdx.y;
-  if (i >= n) return;
+__device__ void intern_claim_one(const DevIndex &ix, const CallBuffers &cb, int round, uint64_t i, int m) {
   if (cb.cls[m][i] != CLS_PENDING) return;
   const uint64_t h = cb.dyn_hash[m][i];
   const uint32_t tag = intern_tag(h);
@@ -1093,11 +1088,16 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
   }
 }
 
-__global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
-  if (cb.state[8] == 0) return;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// (a capped grid striding over the reads: in the usual case -- nothing pending -- a thousand workgroups leave at once
+// instead of forty thousand)
+__global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
+  if (cb.state[8] == 0) return;  // no class was parked in the scratch pool: nothing is pending (the usual case)
   const int m = (int)blockIdx.y;
-  if (i >= cb.n) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cb.n; i += (uint64_t)gridDim.x * blockDim.x)
+    intern_claim_one(ix, cb, round, i, m);
+}
+
+__device__ void intern_verify_one(const DevIndex &ix, const CallBuffers &cb, uint64_t i, int m) {
   if (cb.cls[m][i] != CLS_PENDING) return;
   const uint32_t id = (uint32_t)ix.intern[cb.dyn_pos[m][i]];
   const uint32_t len = cb.dyn_len[m][i];
@@ -1112,6 +1112,13 @@ __global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
   }
   if (same) cb.cls[m][i] = id;
   else atomicAdd((unsigned long long *)&cb.state[9], 1ULL);  // tag collision: next round probes further
+}
+
+__global__ void k_intern_verify(DevIndex ix, CallBuffers cb) {
+  if (cb.state[8] == 0) return;
+  const int m = (int)blockIdx.y;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cb.n; i += (uint64_t)gridDim.x * blockDim.x)
+    intern_verify_one(ix, cb, i, m);
 }
 
 // one unique read key adds 1 to the (segment, class R1, class R2) histogram (open addressing over u64 keys)
@@ -1687,11 +1694,13 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
   if (cb.n == 0) return;
-  hipLaunchKernelGGL(k_intern_claim, dim3(blocks_for(cb.n, 256), cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb, round);
+  const uint32_t full = blocks_for(cb.n, 256);
+  hipLaunchKernelGGL(k_intern_claim, dim3(full < 1024u ? full : 1024u, cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb, round);
 }
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb) {
   if (cb.n == 0) return;
-  hipLaunchKernelGGL(k_intern_verify, dim3(blocks_for(cb.n, 256), cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb);
+  const uint32_t full = blocks_for(cb.n, 256);
+  hipLaunchKernelGGL(k_intern_verify, dim3(full < 1024u ? full : 1024u, cb.paired ? 2 : 1), dim3(256), 0, s, ix, cb);
 }
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid) {
   if (cb.n == 0) return;
