@@ -395,13 +395,10 @@ int enqueue_head(nimble_ctx *c) {
     HIPCHK(hipStreamWaitEvent(s, c->ev[6], 0));
     c->tail_aside = false;
   }
-  HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, s));
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   c->dedup_clean_slots = c->defer.active ? c->dslots : 0;  // a deferred call never touches its own table
-  if (cb.hot) HIPCHK(hipMemsetAsync(cb.hot, 0, (size_t)HOT_KEYS * 8, s));
-  HIPCHK(hipMemsetAsync(c->b_hist_keys.p, 0xFF, c->hist_slots * 8, s));
-  HIPCHK(hipMemsetAsync(c->b_hist_cnt.p, 0, c->hist_slots * 8, s));
-  if (cb.hist_rep) HIPCHK(hipMemsetAsync(cb.hist_rep, 0, c->hist_slots * 4, s));
+  launch_clear_call(s, cb);  // histogram table, state words, hot-key set
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[0], s));
   return NIMBLE_OK;
 }

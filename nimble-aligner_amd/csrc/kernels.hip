@@ -1614,6 +1614,19 @@ __global__ void k_count_verdicts(nimble_align_params p, CallBuffers cb, const ui
   cb.counted[i] = counted;
 }
 
+// head of a call: the histogram table, the state words and the hot-key set cleared by one launch (five separate
+// fills cost a launch each)
+__global__ void k_clear_call(CallBuffers cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= cb.hist_mask) {
+    cb.hist_keys[i] = HIST_EMPTY;
+    cb.hist_cnt[i] = 0;
+    if (cb.hist_rep) cb.hist_rep[i] = 0;
+  }
+  if (i < 16) cb.state[i] = 0;
+  if (cb.hot && i < HOT_KEYS) cb.hot[i] = 0;
+}
+
 // the 16 state words of a call, to page-locked host memory (read by the host after the call's last event)
 __global__ void k_publish_state(const uint64_t *__restrict__ state, uint64_t *__restrict__ host) {
   if (threadIdx.x < 16) host[threadIdx.x] = state[threadIdx.x];
@@ -1769,6 +1782,10 @@ void launch_count_verdicts(hipStream_t s, const nimble_align_params &p, const Ca
 void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb) {
   if (cb.n == 0) return;
   hipLaunchKernelGGL(k_records_unpack, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, rec, cb);
+}
+void launch_clear_call(hipStream_t s, const CallBuffers &cb) {
+  const uint64_t items = cb.hist_mask + 1 > HOT_KEYS ? cb.hist_mask + 1 : HOT_KEYS;
+  hipLaunchKernelGGL(k_clear_call, dim3(blocks_for(items, 256)), dim3(256), 0, s, cb);
 }
 void launch_publish_state(hipStream_t s, const uint64_t *state, uint64_t *host) {
   hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, s, state, host);
