@@ -74,7 +74,16 @@ int nimble_device_count(int *count);
  *      (src/bin/main.rs:121-128, tests/utils.rs:48-51); input is what
  *      utils::get_reference_sequence_data (src/utils.rs:7-24) produces: one ASCII sequence per
  *      library row (fwd and §rev rows interleaved), converted as DnaString::from_acgt_bytes does.
- *      Names stay on the host.  The index is immutable after build and may be shared by contexts. */
+ *      Names stay on the host.
+ *
+ *      Concurrency contract.  The graph, the dictionary and the static colour classes are immutable after build.
+ *      The class table is not: a call whose reads produce an intersection that is no k-mer colour appends that class
+ *      to the index (nimble_index_stats [7]) so that every class has ONE id per content for the life of the index.
+ *      An index may be shared by any number of contexts, on one stream or several, driven from one host thread or
+ *      several (one thread per context; a context itself is not thread-safe): the kernels that append classes are
+ *      chained per index and never overlap, whichever streams they are on, and lookups beside them are safe (a class
+ *      being appended is simply resolved one step later).  Calls on different streams therefore serialise at their
+ *      interning step -- behind the other call's alignment -- and run concurrently everywhere else. */
 int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device,
                        nimble_index **out);
 void nimble_index_free(nimble_index *);

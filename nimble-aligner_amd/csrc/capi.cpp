@@ -85,6 +85,13 @@ struct nimble_index {
   // likelier that somebody else's stream (RCCL's) lands behind the launch stream's persistent kernels.
   hipStream_t copy_stream = nullptr;
   int n_ctx = 0;  // contexts alive on this index
+  // The class table (intern slots, descriptors, id pool) is the one part of the index that calls write.  Claim and
+  // verify kernels of different contexts -- possibly on different streams, enqueued by different host threads -- are
+  // chained through this event so that they never run beside each other: a kernel boundary lies between one context's
+  // claims and the next one's, which is what keeps class ids canonical (one id per content).
+  std::mutex intern_mu;
+  hipEvent_t ev_intern = nullptr;
+  bool intern_chained = false;
   DevIndex dev{};
   DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
@@ -92,6 +99,7 @@ struct nimble_index {
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (ev_intern) (void)hipEventDestroy(ev_intern);
     for (DevBuf *b : {&b_ht, &b_bitmap, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
                       &b_dyn_state})
       b->release();
@@ -381,9 +389,24 @@ int enqueue_route(nimble_ctx *c) {
   launch_route(c->stream, c->cb, world, block_counts, block_first, totals, c->defer.records, c->defer.perm);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->defer.p_counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->defer.p_counts + 256, (uint64_t *)c->b_state.p + 14, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipEventRecord(c->defer.ev_route, c->stream));
   c->defer.counts_world = world;
   c->defer.routed = true;
+  return NIMBLE_OK;
+}
+
+// One round of class interning (claim, then verify behind the kernel boundary), chained behind the interning of
+// every other context of the index (see nimble_index::ev_intern).
+int enqueue_intern_round(nimble_ctx *c, int round) {
+  nimble_index *ix = c->ix;
+  std::lock_guard<std::mutex> lock(ix->intern_mu);
+  if (!ix->ev_intern) HIPCHK(hipEventCreateWithFlags(&ix->ev_intern, hipEventDisableTiming));
+  if (ix->intern_chained) HIPCHK(hipStreamWaitEvent(c->stream, ix->ev_intern, 0));
+  launch_intern_claim(c->stream, ix->dev, c->cb, round);
+  launch_intern_verify(c->stream, ix->dev, c->cb);
+  HIPCHK(hipEventRecord(ix->ev_intern, c->stream));
+  ix->intern_chained = true;
   return NIMBLE_OK;
 }
 
@@ -410,8 +433,10 @@ int enqueue_tail(nimble_ctx *c) {
   HIPCHK(hipEventRecord(c->ev[2], s));
   // class interning, round 0: claim, then verify behind the kernel boundary.  Tag collisions (practically
   // never) leave reads unresolved; finish_call() then runs further rounds and redoes dedup + count.
-  launch_intern_claim(s, c->ix->dev, cb, 0);
-  launch_intern_verify(s, c->ix->dev, cb);
+  {
+    int rc = enqueue_intern_round(c, 0);
+    if (rc) return rc;
+  }
   HIPCHK(hipEventRecord(c->ev[3], s));
   if (c->defer.active) {
     // the dedup verdicts come from the keys' owners: the call stays open until nimble_count_verdicts
@@ -488,6 +513,18 @@ int finish_call(nimble_ctx *c) {
     int rc = fetch_state(c);
     if (rc) return rc;
     const uint64_t err = c->h_state[10];
+    if (c->h_state[14] != 0) {
+      // k_pack met offsets it could not trust (device-resident inputs are validated where they are read)
+      HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 14, 0, 8, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      c->finished = true;
+      c->h_c1.clear();
+      c->h_c2.clear();
+      c->h_cnt.clear();
+      c->h_seg.clear();
+      c->h_rep.clear();
+      return fail(NIMBLE_E_INVALID, "offsets not monotone or a read longer than max_len (found on the device)");
+    }
     if (err & ERR_SCRATCH) {
       if (c->attempt >= 3 || c->scratch_cap >= 0xFFFFFF00ULL)
         return fail(NIMBLE_E_OVERFLOW, "class scratch pool overflow (raise NIMBLE_SCRATCH_PER_READ)");
@@ -507,9 +544,8 @@ int finish_call(nimble_ctx *c) {
       for (int round = 1; c->h_state[9] != 0; ++round) {
         if (round > 64) return fail(NIMBLE_E_INTERNAL, "class interning did not converge");
         HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 9, 0, 8, c->stream));
-        launch_intern_claim(c->stream, c->ix->dev, c->cb, round);
-        launch_intern_verify(c->stream, c->ix->dev, c->cb);
-        rc = mark_done(c);
+        rc = enqueue_intern_round(c, round);
+        if (!rc) rc = mark_done(c);
         if (!rc) rc = fetch_state(c);
         if (rc) return rc;
         if (c->h_state[10] & (ERR_CLASS_CAP | ERR_IDS_CAP))
@@ -956,7 +992,11 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   if (c->hist_slots == 0) c->hist_slots = pow2_at_least(env_u64("NIMBLE_HIST_SLOTS", 1ULL << 18));
   need(c->b_hist_keys, c->hist_slots * 8);
   need(c->b_hist_cnt, c->hist_slots * 8);
-  need(c->b_state, 16 * 8);
+  {
+    const void *before = c->b_state.p;
+    need(c->b_state, 16 * 8);
+    if (rc == NIMBLE_OK && c->b_state.p != before) HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, c->stream));
+  }
   static const bool hot_keys = env_u64("NIMBLE_HOT_KEYS", 1) != 0;
   if (hot_keys) need(c->b_hot, (size_t)HOT_KEYS * 8);
   if (rc != NIMBLE_OK) return rc;
@@ -1173,8 +1213,13 @@ int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uin
   if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0] || (in->paired && (!in->len[1] || !in->pre[1]))))
     return fail(NIMBLE_E_INVALID, "nimble_route_records: packed arrays missing");
   HIPCHK(hipSetDevice(c->ix->device));
-  int rc = c->b_state.ensure(16 * 8, &c->bytes);
-  if (rc) return rc;
+  int rc = NIMBLE_OK;
+  {
+    const void *before = c->b_state.p;
+    rc = c->b_state.ensure(16 * 8, &c->bytes);
+    if (rc) return rc;
+    if (c->b_state.p != before) HIPCHK(hipMemsetAsync(c->b_state.p, 0, 16 * 8, c->stream));
+  }
   const uint64_t cells = (uint64_t)route_grid() * world;
   rc = c->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &c->bytes);
   if (rc) return rc;
@@ -1187,8 +1232,9 @@ int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uin
   HIPCHK(hipGetLastError());
   if (!c->defer.ev_route) HIPCHK(hipEventCreateWithFlags(&c->defer.ev_route, hipEventDisableTiming));
   if (!c->defer.p_counts)
-    HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 256 * sizeof(uint64_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 257 * sizeof(uint64_t), hipHostMallocDefault));
   HIPCHK(hipMemcpyAsync(c->defer.p_counts, totals, world * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->defer.p_counts + 256, (uint64_t *)c->b_state.p + 14, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipEventRecord(c->defer.ev_route, c->stream));
   c->defer.counts_world = world;
   // counts == NULL: asynchronous; nimble_route_counts waits for exactly this routing and hands the counts over
@@ -1235,7 +1281,7 @@ int nimble_ctx_defer_dedup(nimble_ctx *c, uint32_t world, uint64_t *records, uin
   int rc = c->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &c->bytes);
   if (rc) return rc;
   if (!c->defer.ev_route) HIPCHK(hipEventCreateWithFlags(&c->defer.ev_route, hipEventDisableTiming));
-  if (!c->defer.p_counts) HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 256 * sizeof(uint64_t), hipHostMallocDefault));
+  if (!c->defer.p_counts) HIPCHK(hipHostMalloc((void **)&c->defer.p_counts, 257 * sizeof(uint64_t), hipHostMallocDefault));
   c->defer.world = world;
   c->defer.records = records;
   c->defer.perm = perm;
@@ -1248,6 +1294,11 @@ int nimble_route_counts(nimble_ctx *c, uint64_t *counts) {
   HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipEventSynchronize(c->defer.ev_route));  // the routing only; whatever was enqueued behind it keeps running
   std::copy(c->defer.p_counts, c->defer.p_counts + c->defer.counts_world, counts);
+  if (c->defer.p_counts[256] != 0) {  // the pack that produced these keys met offsets it could not trust
+    c->defer.p_counts[256] = 0;
+    HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 14, 0, 8, c->stream));
+    return fail(NIMBLE_E_INVALID, "offsets not monotone or a read longer than max_len (found on the device)");
+  }
   return NIMBLE_OK;
 }
 

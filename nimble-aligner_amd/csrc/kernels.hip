@@ -59,9 +59,9 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__ r1, const uint64_t *__restrict__ off1,
                                                      const uint8_t *__restrict__ r2, const uint64_t *__restrict__ off2,
-                                                     uint32_t fixed_len, uint32_t rpb, uint32_t tile_bytes,
-                                                     uint32_t min_len, const double *__restrict__ plog,
-                                                     CallBuffers cb) {
+                                                     uint32_t fixed_len, uint32_t max_len, uint32_t rpb,
+                                                     uint32_t tile_bytes, uint32_t min_len,
+                                                     const double *__restrict__ plog, CallBuffers cb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint64_t n = cb.n;
@@ -76,6 +76,12 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     const uint64_t *off = m ? off2 : off1;
     uint64_t s = off ? off[r0] : r0 * fixed_len;
     uint64_t e = off ? off[r0 + cnt] : (r0 + cnt) * fixed_len;
+    // offsets handed over in device memory were never seen by the host: a span that does not fit the tile (non-monotone
+    // offsets, a read longer than max_len) is cut here and reported through the call's error word
+    if (e < s || e - s > (uint64_t)cnt * max_len) {
+      e = s;
+      if (tid == 0) atomicOr((unsigned long long *)&cb.state[14], 1ULL);
+    }
     uintptr_t a = (uintptr_t)(src + s);
     uintptr_t a0 = a & ~(uintptr_t)15;
     shift[m] = (uint32_t)(a - a0);
@@ -100,7 +106,14 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
   for (int m = 0; m < nm; ++m) {
     const uint64_t *off = m ? off2 : off1;
     uint64_t s = off ? off[r] : r * fixed_len;
-    L[m] = off ? (uint32_t)(off[r + 1] - s) : fixed_len;
+    uint64_t e = off ? off[r + 1] : s + fixed_len;
+    // the read must lie inside what the block staged: [seg_start, seg_start + cnt * max_len)
+    if (e < s || e - s > max_len || s < seg_start[m] || e - seg_start[m] > (uint64_t)cnt * max_len) {
+      atomicOr((unsigned long long *)&cb.state[14], 1ULL);
+      s = seg_start[m];
+      e = s;  // an empty read: ShortRead, nothing is read beyond the tile
+    }
+    L[m] = (uint32_t)(e - s);
     p[m] = lds + (size_t)m * tile_bytes + shift[m] + (uint32_t)(s - seg_start[m]);
   }
   const uint32_t total = L[0] + L[1];
@@ -1076,7 +1089,10 @@ __device__ void intern_claim_one(const DevIndex &ix, const CallBuffers &cb, int 
       make_class_desc(src, len, desc);
       ix.cls_off[id] = off;
       ix.cls_desc[id] = make_uint4(desc[0], desc[1], desc[2], desc[3]);
-      ix.intern[pos] = ((uint64_t)tag << 32) | id;
+      // the content is in memory before the id is: a lookup that sees the id (k_align, any stream) finds the class
+      // behind it.  (Claim / verify kernels of different contexts never overlap, capi.cpp serialises them per index.)
+      __threadfence();
+      __hip_atomic_store(&ix.intern[pos], ((uint64_t)tag << 32) | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cb.dyn_pos[m][i] = (uint32_t)pos;
       return;
     }
@@ -1099,7 +1115,14 @@ __global__ void k_intern_claim(DevIndex ix, CallBuffers cb, int round) {
 
 __device__ void intern_verify_one(const DevIndex &ix, const CallBuffers &cb, uint64_t i, int m) {
   if (cb.cls[m][i] != CLS_PENDING) return;
-  const uint32_t id = (uint32_t)ix.intern[cb.dyn_pos[m][i]];
+  const uint32_t id = (uint32_t)__hip_atomic_load(&ix.intern[cb.dyn_pos[m][i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (id == INTERN_PENDING) {
+    // claimed but not yet published (only a claim running beside this kernel could leave that): not a collision --
+    // the next round looks at the SAME slot again (it starts one past dyn_pos)
+    cb.dyn_pos[m][i] = (uint32_t)(((uint64_t)cb.dyn_pos[m][i] + ix.intern_mask) & ix.intern_mask);
+    atomicAdd((unsigned long long *)&cb.state[9], 1ULL);
+    return;
+  }
   const uint32_t len = cb.dyn_len[m][i];
   uint4 d0 = make_uint4(0, 0, 0, 0);
   if (id < ix.cls_cap) d0 = ix.cls_desc[id];
@@ -1666,7 +1689,7 @@ __global__ void k_clear_call(CallBuffers cb) {
     cb.hist_cnt[i] = 0;
     if (cb.hist_rep) cb.hist_rep[i] = 0;
   }
-  if (i < 16) cb.state[i] = 0;
+  if (i < 16 && i != 14) cb.state[i] = 0;  // [14] latches input errors found by k_pack until the host has reported them
   if (cb.hot && i < HOT_KEYS) cb.hot[i] = 0;
 }
 
@@ -1700,8 +1723,8 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
   while (rpb > 1 && (uint64_t)nm * ((uint64_t)rpb * max_len + 48) > budget) rpb >>= 1;
   uint32_t tile_bytes = (uint32_t)((((uint64_t)rpb * max_len + 32) + 15) & ~15ULL);
   uint32_t grid = blocks_for(cb.n, rpb);
-  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(PACK_BLOCK), nm * tile_bytes, s, r1, off1, r2, off2, fixed_len, rpb,
-                     tile_bytes, min_len, plog, cb);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(PACK_BLOCK), nm * tile_bytes, s, r1, off1, r2, off2, fixed_len, max_len,
+                     rpb, tile_bytes, min_len, plog, cb);
 }
 
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as ora
-from test_gpu_parity import Case, make_cfg, nim, params_from, synth
+from test_gpu_parity import Case, fnv_class, make_cfg, nim, params_from, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -144,3 +144,97 @@ def test_dominant_keys_among_ordinary_reads(paired):
     o = synth.fixed_offsets(n, 150)
     res = case.check(r1.reshape(-1), o, None if r2 is None else r2.reshape(-1), None if r2 is None else o)
     assert res.counters["unique_keys"] < 0.8 * n
+
+
+def test_device_offsets_are_validated_on_the_device():
+    """Offsets handed over in device memory never pass the host's check (nimble_hip.h: NIMBLE_MEM_DEVICE buffers are
+    used in place): k_pack itself refuses a read longer than max_len and offsets that run backwards, touches nothing
+    outside its tile, and the call reports NIMBLE_E_INVALID; the context stays usable."""
+    torch = pytest.importorskip("torch")
+    names, seqs = synth.make_library(16)
+    case = Case(names, seqs, make_cfg())
+    reads = synth.make_reads(seqs, 4096)
+    n, L = reads.shape
+    flat = torch.from_numpy(reads.reshape(-1).copy()).to("cuda:0")
+    good = np.arange(n + 1, dtype=np.uint64) * L
+    p = params_from(case.cfg)
+    ctx = nim.Context(case.dindex)
+
+    def run(off_np, max_len):
+        off = torch.from_numpy(off_np.astype(np.int64)).to("cuda:0")
+        torch.cuda.synchronize()
+        ctx.call(p, flat, off, n=n, max_len=max_len, mem=nim.MEM_DEVICE)
+        return ctx.histogram()
+
+    want = run(good, L)
+    assert want
+    too_long = good.copy()
+    too_long[1000] += 40                        # read 999 has L + 40 bases, read 1000 has L - 40
+    backwards = good.copy()
+    backwards[2000], backwards[2001] = backwards[2001], backwards[2000]
+    for bad in (too_long, backwards):           # (offsets beyond the buffer are the caller's contract, as with any pointer)
+        with pytest.raises(nim.NimbleError) as e:
+            run(bad, L)
+        assert e.value.code == -1 and "max_len" in str(e.value)
+        assert run(good, L) == want             # the error does not stick to the context
+
+
+def test_two_streams_intern_the_same_new_classes():
+    """Two contexts with their OWN streams on one index (what include/nimble_hip.h allows and the BAM consumer pool
+    does), driven by two host threads at once, both meeting the same classes for the first time, with
+    require_valid_pair on: class ids stay canonical (one id per content -- filter_pair compares ids) and both calls
+    equal the oracle."""
+    import threading
+
+    names, seqs = synth.make_library(96)
+    r1, r2 = synth.make_reads(seqs, 60000, paired=True)
+    o = synth.fixed_offsets(r1.shape[0], r1.shape[1])
+    cfg_obj = make_cfg(score_percent=0.08, score_threshold=12, num_mismatches=1, require_valid_pair=True)
+    base = Case(names, seqs, cfg_obj)
+    res = ora.call(base.oindex, base.ref, base.cfg, r1.reshape(-1), o, r2.reshape(-1), o, keep_per_read=True)
+    p = params_from(base.cfg)
+    row_names, row_seqs = synth.expand_rows(names, seqs)
+    new_classes = 0
+    for attempt in range(3):                     # a fresh class table every time: everything is new again
+        idx = nim.Index(row_seqs)
+        static = idx.stats()["classes"]
+        ctxs = [nim.Context(idx), nim.Context(idx)]
+        assert ctxs[0].stream_ptr() != ctxs[1].stream_ptr()
+        errs = []
+        gate = threading.Barrier(2)
+
+        def work(c):
+            try:
+                gate.wait()
+                c.call(p, r1.reshape(-1), o, r2.reshape(-1), o)
+                c.synchronize()
+            except Exception as e:               # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        content = {}
+        for c in ctxs:
+            for m in range(2):
+                rec = c.read_records(m)
+                np.testing.assert_array_equal(rec["reason"], res.per_read["reason"][m])
+                np.testing.assert_array_equal(rec["score"], res.per_read["score"][m])
+                cls = rec["cls"]
+                has = cls != nim.CLASS_NONE
+                for cid in np.unique(cls[has]):
+                    content.setdefault(int(cid), tuple(idx.eq_class(int(cid))))
+                hmap = {cid: fnv_class(list(v)) for cid, v in content.items()}
+                got = np.array([hmap[int(x)] for x in cls[has]], dtype=np.uint64)
+                np.testing.assert_array_equal(got, res.per_read["class_hash"][m][has])
+            np.testing.assert_array_equal(c.read_records(0)["counted"], res.per_read["counted"])
+        # one id per content, across both contexts
+        assert len(set(content.values())) == len(content)
+        new_classes += sum(1 for cid in content if cid >= static)
+        for c in ctxs:
+            c.close()
+        idx.close()
+    assert new_classes > 0, "the input produced no class that had to be interned: the test exercises nothing"
