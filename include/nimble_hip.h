@@ -86,6 +86,7 @@ int nimble_device_count(int *count);
  *      interning step -- behind the other call's alignment -- and run concurrently everywhere else. */
 int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device,
                        nimble_index **out);
+/* An index freed while contexts on it are alive is released when the last of them is freed. */
 void nimble_index_free(nimble_index *);
 /* stats[0]=distinct k-mers [1]=unitigs [2]=static classes [3]=unitig bases [4]=static class entries
  * [5]=hash slots [6]=device bytes [7]=dynamic classes interned so far */

@@ -433,6 +433,7 @@ class Context:
                     prefiltered=c[6], dynamic_classes=c[7])
 
     def timing(self):
+        """Device ms of the stages of the last call (HIP events on the launch stream)."""
         t = (C.c_float * 6)()
         _check(hip_lib().nimble_call_timing(self.h, t))
         return dict(pack=t[0], align=t[1], intern=t[2], dedup=t[3], count=t[4], total=t[5])

@@ -92,15 +92,17 @@ struct nimble_index {
   std::mutex intern_mu;
   hipEvent_t ev_intern = nullptr;
   bool intern_chained = false;
+  hipStream_t intern_last = nullptr;  // the stream ev_intern was last recorded on
+  bool released = false;  // nimble_index_free was called while contexts were alive: the last context frees the index
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_l1, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_intern) (void)hipEventDestroy(ev_intern);
-    for (DevBuf *b : {&b_ht, &b_bitmap, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
+    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
                       &b_dyn_state})
       b->release();
   }
@@ -407,6 +409,7 @@ int enqueue_intern_round(nimble_ctx *c, int round) {
   launch_intern_verify(c->stream, ix->dev, c->cb);
   HIPCHK(hipEventRecord(ix->ev_intern, c->stream));
   ix->intern_chained = true;
+  ix->intern_last = c->stream;
   return NIMBLE_OK;
 }
 
@@ -694,6 +697,8 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   };
   up(ix->b_ht, fi.ht);
   up(ix->b_bitmap, fi.bitmap);
+  static const bool use_l1 = env_u64("NIMBLE_FILTER_L1", 1) != 0;
+  if (use_l1 && !fi.l1.empty()) up(ix->b_l1, fi.l1);
   up(ix->b_rec, fi.node_rec);
   up(ix->b_ledge, fi.node_ledge);
   up(ix->b_unitig, fi.unitig);
@@ -729,6 +734,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.ht_log2 = fi.ht_log2;
   d.bitmap = ix->b_bitmap.as<uint4>();
   d.bm_lines_log2 = fi.bm_lines_log2;
+  d.l1 = ix->b_l1.p ? ix->b_l1.as<uint32_t>() : nullptr;
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
@@ -765,6 +771,15 @@ int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32
 
 void nimble_index_free(nimble_index *ix) {
   if (!ix) return;
+  {
+    // contexts keep a pointer to their index: an index freed first (a garbage collector picks its own order) stays
+    // until its last context has gone
+    std::lock_guard<std::mutex> lock(ix->intern_mu);
+    if (ix->n_ctx > 0) {
+      ix->released = true;
+      return;
+    }
+  }
   (void)hipSetDevice(ix->device);
   delete ix;
 }
@@ -842,7 +857,10 @@ int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
   }
   c->want_counters = (int)env_u64("NIMBLE_COUNTERS", 0);
   c->tail_aside_grid = (uint32_t)std::min<uint64_t>(env_u64("NIMBLE_DEDUP_ASIDE", 1280), 1u << 20);
-  ix->n_ctx++;
+  {
+    std::lock_guard<std::mutex> lock(ix->intern_mu);
+    ix->n_ctx++;
+  }
   *out = c;
   return NIMBLE_OK;
 }
@@ -852,8 +870,22 @@ void nimble_ctx_free(nimble_ctx *c) {
   (void)hipSetDevice(c->ix->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-  c->ix->n_ctx--;
+  {
+    // the interning this context enqueued has finished; nobody may wait on an event of a stream that is about to go
+    std::lock_guard<std::mutex> lock(c->ix->intern_mu);
+    if (c->ix->intern_last == c->stream) {
+      c->ix->intern_chained = false;
+      c->ix->intern_last = nullptr;
+    }
+  }
+  nimble_index *ix = c->ix;
   delete c;
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> lock(ix->intern_mu);
+    last = --ix->n_ctx == 0 && ix->released;
+  }
+  if (last) delete ix;
 }
 
 void *nimble_ctx_stream(nimble_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -230,7 +230,14 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
       heads.push_back((uint32_t)i);
       for (uint32_t c = (uint32_t)i; c != UINT32_MAX; c = next[c]) seen[c] = 1;
     }
-  std::sort(heads.begin(), heads.end());
+  // Node ids follow the library, not the k-mer order: unitigs are numbered by the first row of their colour class (rows of
+  // one gene family are adjacent, forward and reverse rows interleaved), then by head k-mer.  A read's walk stays inside
+  // its family, so reads grouped by seed node (sorted inputs, BAM groups) keep to one stretch of the node records -- the
+  // stretch an XCD works on stays in its L2 however large the library is.
+  std::sort(heads.begin(), heads.end(), [&](uint32_t a, uint32_t b) {
+    const uint32_t ra = out.col_ids[out.col_off[colour[a]]], rb = out.col_ids[out.col_off[colour[b]]];
+    return ra != rb ? ra < rb : a < b;
+  });
 
   timer.lap("chains");
   // 4. unitigs
@@ -332,18 +339,31 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND * 2.0 > 0.16 * 128.0 * (double)(1ull << out.bm_lines_log2))
     ++out.bm_lines_log2;
   out.bitmap.assign((size_t)4 << out.bm_lines_log2, 0);
+  // first level in front of it: one bit per possible value of the 12 shared bases (4^12 bits = 2 MiB, small enough to
+  // live in an XCD's L2): set when ANY library k-mer can be asked under that value.  A round whose bit is clear has no
+  // candidate at all, and its filter line (a fetch from beyond L2) is never loaded.
+  out.l1.assign((size_t)1 << (2 * SCAN_SHARED - 5), 0);
   parallel_slices(n, threads, [&](unsigned, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
       const uint32_t bits = round_bits(kmers[i]);
       const uint32_t half = (bits >> 12) & 1u;
       const uint32_t b1 = (bits & 63u) + 64u * half, b2 = ((bits >> 6) & 63u) + 64u * half;
       for (uint32_t j = 0; j < SCAN_ROUND; ++j) {
-        const uint64_t line = round_line(round_shared_of_kmer(kmers[i], j), out.bm_lines_log2);
+        const uint64_t shared = round_shared_of_kmer(kmers[i], j);
+        const uint64_t line = round_line(shared, out.bm_lines_log2);
         __atomic_fetch_or(&out.bitmap[line * 4 + (b1 >> 5)], 1u << (b1 & 31), __ATOMIC_RELAXED);
         __atomic_fetch_or(&out.bitmap[line * 4 + (b2 >> 5)], 1u << (b2 & 31), __ATOMIC_RELAXED);
+        __atomic_fetch_or(&out.l1[shared >> 5], 1u << (shared & 31), __ATOMIC_RELAXED);
       }
     }
   });
+  {
+    // worth its L2 space only while it rejects most rounds of a read that is not from the library
+    uint64_t set = 0;
+    for (uint32_t w : out.l1) set += (uint64_t)__builtin_popcount(w);
+    out.l1_density = (double)set / (double)((uint64_t)out.l1.size() * 32);
+    if (out.l1_density > 0.5) std::vector<uint32_t>().swap(out.l1);
+  }
   timer.lap("presence filter");
   // 7. class descriptors
   out.cls_desc.assign(out.n_colours * 4, 0);

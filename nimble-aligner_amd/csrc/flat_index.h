@@ -126,6 +126,9 @@ struct FlatIndex {
   // round-anchored presence filter (see round_line / round_bit): lines of 128 bits
   std::vector<uint32_t> bitmap;      // 4 x u32 per line
   uint32_t bm_lines_log2 = 0;
+  // first level of the filter: one bit per value of the 12 shared bases (empty when more than half the bits are set)
+  std::vector<uint32_t> l1;
+  double l1_density = 0.0;
   // node record, one 64-byte line per unitig so that a hop costs one dependent memory level and the
   // class intersection needs no load at all:
   //   u32[0]      = len (bases, low 24 bits) | exts (lext | rext<<4) << 24

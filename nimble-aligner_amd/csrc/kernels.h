@@ -22,6 +22,7 @@ struct DevIndex {
   uint32_t ht_log2;
   const uint4 *bitmap;      // round-anchored presence filter, one 128-bit line per uint4 (flat_index.h)
   uint32_t bm_lines_log2;
+  const uint32_t *l1;       // may be NULL: first level of the filter, one bit per value of the 12 shared bases (2 MiB)
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;
@@ -82,8 +83,9 @@ struct CallBuffers {
   uint64_t *hist_cnt;
   uint64_t hist_mask;
   // [0..7] = counters of nimble_call_counters, [8]=scratch used [9]=unresolved interns
-  // [10]=error flags [11]=histogram entries (compaction) [12]=align tile counter [13]=duplicates met by the dedup
-  // sample [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len; cleared by the host)
+  // [10]=error flags [11]=histogram entries (compaction) [12]=align tile counter
+  // [13]=free [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len;
+  // cleared by the host) [15]=duplicates met by the dedup sample
   uint64_t *state;
 };
 

@@ -393,37 +393,47 @@ __device__ __forceinline__ bool probe_direct(const DevIndex &ix, Lane &ln, uint3
   return false;
 }
 
-// One round of the seed scan at kmer_pos (<= last_kmer_pos): SCAN_ROUND positions at stride 3, answered by ONE
-// 16-byte line of the presence filter selected by the 12 bases all 7 k-mers share; candidates are verified in the
-// dictionary in read order.  Found: kmer_pos / node / off are set.  Not found: kmer_pos moves past the round.
-__device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
-                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off) {
-  // one round: SCAN_ROUND positions at stride 3, answered by ONE 16-byte line of the presence filter,
-  // selected by the 12 bases all 7 k-mers share
+// The filter's answer for one round of the seed scan at kmer_pos (<= last_kmer_pos): bit i = the k-mer at
+// kmer_pos + 3i may be in the dictionary.  SCAN_ROUND positions at stride 3 are answered by ONE 16-byte line of the
+// presence filter, selected by the 12 bases all 7 k-mers share; positions beyond the last k-mer are masked off.
+// FIRST: the scan for the first seed of a mate (most of those mates are not from the library at all): the L2-resident
+// first level is asked before the filter line is fetched; a re-seed inside a walk goes to the line at once.
+__device__ __forceinline__ uint32_t round_maybe(const DevIndex &ix, const uint64_t *rd, uint32_t base0, uint32_t kmer_pos,
+                                                uint32_t last_kmer_pos, bool FIRST = false) {
   uint32_t maybe = 0;
-  {
-    const uint32_t span = KMER + 3u * (SCAN_ROUND - 1);            // 48 bases
-    const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;      // bases of the mate from kmer_pos on
-    uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
-    const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
-    const uint64_t tail =
-        extra ? (lds_bits(ln.rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
-    const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
-    const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
+  const uint32_t span = KMER + 3u * (SCAN_ROUND - 1);            // 48 bases
+  const uint32_t avail = (last_kmer_pos + KMER) - kmer_pos;      // bases of the mate from kmer_pos on
+  uint64_t km = lds_bits(rd, base0 + kmer_pos, KMER);
+  if (FIRST && ix.l1) {
+    const uint32_t sh = (uint32_t)km & ((1u << (2u * SCAN_SHARED)) - 1u);
+    if (!((ix.l1[sh >> 5] >> (sh & 31u)) & 1u)) return 0u;
+  }
+  const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
+  const uint64_t tail = extra ? (lds_bits(rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
+  const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
+  const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
 #pragma unroll
-    for (int i = 0; i < (int)SCAN_ROUND; ++i) {
-      const uint32_t bb = round_bits(km);
-      const uint64_t hw = (bb >> 12) & 1u ? half1 : half0;
-      maybe |= (uint32_t)((hw >> (bb & 63u)) & (hw >> ((bb >> 6) & 63u)) & 1ULL) << i;
-      if (i + 1 < (int)SCAN_ROUND) {
-        const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
-        km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
-      }
+  for (int i = 0; i < (int)SCAN_ROUND; ++i) {
+    const uint32_t bb = round_bits(km);
+    const uint64_t hw = (bb >> 12) & 1u ? half1 : half0;
+    maybe |= (uint32_t)((hw >> (bb & 63u)) & (hw >> ((bb >> 6) & 63u)) & 1ULL) << i;
+    if (i + 1 < (int)SCAN_ROUND) {
+      const uint32_t sh = 2u * (span - KMER) - 6u * (uint32_t)(i + 1);
+      km = ((km << 6) | ((tail >> sh) & 63ULL)) & KMER_MASK;
     }
   }
   const uint32_t valid = last_kmer_pos - kmer_pos;  // positions kmer_pos + 3i <= last  <=>  3i <= valid
   const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
-  maybe &= (1u << nvalid) - 1u;
+  return maybe & ((1u << nvalid) - 1u);
+}
+
+// One round of the seed scan at kmer_pos (<= last_kmer_pos): candidates of round_maybe are verified in the
+// dictionary in read order.  Found: kmer_pos / node / off are set.  Not found: kmer_pos moves past the round.
+__device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
+                                           uint32_t last_kmer_pos, uint32_t &node, uint32_t &off, bool first = false) {
+  uint32_t maybe = round_maybe(ix, ln.rd, base0, kmer_pos, last_kmer_pos, first);
+  const uint32_t valid = last_kmer_pos - kmer_pos;
+  const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
   uint32_t examined = nvalid;
   bool found = false;
   while (maybe) {  // candidates in read order (filter false positives or a real seed); usually none
@@ -459,7 +469,7 @@ __device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_
 // (it hits for most on-target reads); after a miss PROBE_BATCH independent probes are kept in flight.
 __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
                                            uint32_t last_kmer_pos, uint32_t &node, uint32_t &off,
-                                           bool skip_direct = false) {
+                                           bool skip_direct = false, bool first = false) {
   if (kmer_pos > last_kmer_pos) return false;
   if (!skip_direct) {
     const uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
@@ -475,7 +485,7 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
     kmer_pos += 3;
   }
   while (kmer_pos <= last_kmer_pos)
-    if (scan_round(ix, ln, base0, kmer_pos, last_kmer_pos, node, off)) return true;
+    if (scan_round(ix, ln, base0, kmer_pos, last_kmer_pos, node, off, first)) return true;
   return false;
 }
 
@@ -611,9 +621,11 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         koff = (uint32_t)pre_seed;
       } else if (first && pre == 1u) {
         kmer_pos = 3;
-        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, true);
+        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, true, true);
       } else {
-        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff);
+        // (a re-seed: the scan rounds start at kmer_pos itself -- the k-mer there holds the base that just failed, a
+        // direct probe of it is a wasted fetch; the first seed of mate 1 still goes through the direct probe)
+        have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, !first, first);
       }
       if (!have) {
         done = true;
@@ -1286,7 +1298,7 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
       for (uint32_t w = 0; w < nw; ++w) diff |= rd_key(cb, w, i) ^ rd_key(cb, w, j);
       if (diff == 0) {
         if (mode != 0 && !look) cb.hot[hot_slot] = h;
-        if (mode == 1) atomicAdd((unsigned long long *)&cb.state[13], 1ULL);
+        if (mode == 1) atomicAdd((unsigned long long *)&cb.state[15], 1ULL);
         if (j < i) atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
         else if (look && he && nw <= HC_WORDS && atomicCAS((uint32_t *)&he->state, 0u, 1u) == 0u) {
           he->h = h;
@@ -1315,7 +1327,7 @@ __global__ __launch_bounds__(256) void k_dedup(nimble_align_params p, CallBuffer
   // The sample launch (the last reads, g_begin == 0 of a split launch) counts the duplicates it meets; only when it
   // met some does the main launch pay for the look-before-atomic machinery.
   const bool is_sample = cb.hot && g_begin == 0 && g_end < n;
-  const int mode = !cb.hot ? 0 : is_sample ? 1 : (g_begin != 0 && cb.state[13] >= 4 ? 2 : 0);
+  const int mode = !cb.hot ? 0 : is_sample ? 1 : (g_begin != 0 && cb.state[15] >= 4 ? 2 : 0);
   HotEntry *hc = mode == 2 ? s_hot : nullptr;
   // per-block callset counters: plain calls only (a representative read per entry, BAM mode, needs the global max)
   __shared__ HotCls s_cls[HCLS_ENTRIES];
@@ -1727,6 +1739,16 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
                      rpb, tile_bytes, min_len, plog, cb);
 }
 
+static int resident_blocks(const void *fn, size_t lds) {
+  int per_cu = 0, dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, ALIGN_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (cus < 1) cus = 256;
+  const int g = per_cu * cus;
+  return g > ALIGN_GRID ? ALIGN_GRID : g;
+}
+
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
                   int want_counters, int grid_pct) {
   if (cb.n == 0) return;
@@ -1737,9 +1759,6 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   static int resident_cache[128] = {0};
   int key = (int)(lds / 2048) & 127;
   if (resident_cache[key] == 0) {
-    int per_cu = 0, dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (lds > 48 * 1024) {  // long reads: opt in to more dynamic LDS than the default limit
       const void *all[8] = {(const void *)k_align<true, true, true>,   (const void *)k_align<true, true, false>,
                             (const void *)k_align<true, false, true>,  (const void *)k_align<true, false, false>,
@@ -1747,12 +1766,7 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                             (const void *)k_align<false, false, true>, (const void *)k_align<false, false, false>};
       for (const void *f : all) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align<true, true, true>, ALIGN_BLOCK, lds) != hipSuccess ||
-        per_cu < 1)
-      per_cu = 4;
-    if (cus < 1) cus = 256;
-    int g = per_cu * cus;
-    resident_cache[key] = g > ALIGN_GRID ? ALIGN_GRID : g;
+    resident_cache[key] = resident_blocks((const void *)k_align<true, true, true>, lds);
   }
   // grid_pct < 100 leaves block slots free on every CU: a persistent grid that fills the chip would keep the
   // kernels of another stream (RCCL's exchange) waiting until it ends

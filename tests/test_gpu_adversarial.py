@@ -187,7 +187,26 @@ def test_two_streams_intern_the_same_new_classes():
     import threading
 
     names, seqs = synth.make_library(96)
-    r1, r2 = synth.make_reads(seqs, 60000, paired=True)
+    r1, r2 = synth.make_reads(seqs, 40000, paired=True)
+    # Gadgets whose reads end in a class that is no k-mer's colour: A = P + Q, B holds P, C holds Q, D holds the
+    # junction; a read across the junction visits colours {A,B} {A,B,D} {A,D} {A,C,D} {A,C}: intersection {A}, and A
+    # has no k-mer of its own.  Both mates are cut from the forward strand so that a valid pair exists at all.
+    rng = np.random.default_rng(2024)
+    names, seqs = list(names), list(seqs)
+    g1, g2 = [], []
+    for g in range(150):
+        P, Q = rnd(rng, 300), rnd(rng, 300)
+        A = P + Q
+        names += ["G%03d-%s" % (g, t) for t in "ABCD"]
+        seqs += [A, rnd(rng, 100) + P, Q + rnd(rng, 100), A[260:340]]
+        for _ in range(120):
+            a, b = (int(x) for x in rng.integers(215, 236, size=2))
+            g1.append(np.frombuffer(A[a:a + 150].encode(), dtype=np.uint8))
+            g2.append(np.frombuffer(A[b:b + 150].encode(), dtype=np.uint8))
+    r1 = np.concatenate([r1, np.stack(g1)])
+    r2 = np.concatenate([r2, np.stack(g2)])
+    order = rng.permutation(r1.shape[0])
+    r1, r2 = np.ascontiguousarray(r1[order]), np.ascontiguousarray(r2[order])
     o = synth.fixed_offsets(r1.shape[0], r1.shape[1])
     cfg_obj = make_cfg(score_percent=0.08, score_threshold=12, num_mismatches=1, require_valid_pair=True)
     base = Case(names, seqs, cfg_obj)
@@ -238,3 +257,24 @@ def test_two_streams_intern_the_same_new_classes():
             c.close()
         idx.close()
     assert new_classes > 0, "the input produced no class that had to be interned: the test exercises nothing"
+
+
+def test_index_freed_before_its_context():
+    """A garbage collector frees in its own order: an index released while a context on it is alive must stay until
+    that context has gone (the context used to read the freed index, and HIP kept the error for the next caller)."""
+    names, seqs = synth.make_library(8)
+    _, row_seqs = synth.expand_rows(names, seqs)
+    idx = nim.Index(row_seqs)
+    ctx = nim.Context(idx)
+    reads = synth.make_reads(seqs, 1024)
+    p = nim.AlignParams.make(0.33, 50, 0)
+    ctx.call(p, reads.reshape(-1), None, n=1024, fixed_len=150)
+    want = ctx.histogram()
+    idx.close()                                    # the index first ...
+    ctx.call(p, reads.reshape(-1), None, n=1024, fixed_len=150)
+    assert ctx.histogram() == want                 # ... the context still works on it
+    ctx.close()                                    # ... and takes the index with it
+    idx2 = nim.Index(row_seqs)                     # the next user of the device finds no stale HIP error
+    c2 = nim.Context(idx2)
+    c2.call(p, reads.reshape(-1), None, n=1024, fixed_len=150)
+    assert c2.histogram() == want
