@@ -375,7 +375,8 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
       // a class wider than the 64-row mask form gets a bitmap over the rows it spans (allele families: the rows of
       // a gene are neighbours, so a class of 100 alleles spans a few hundred rows): the device intersects such
       // classes word by word instead of searching id lists
-      const uint32_t first = out.col_ids[o], span = out.col_ids[o + l - 1] - first + 1u;
+      // (the bitmap starts at a multiple of 64 rows: a 64-row window at a multiple of 64 is then ONE word of it)
+      const uint32_t first = out.col_ids[o] & ~63u, span = out.col_ids[o + l - 1] - first + 1u;
       if (l && span <= CLS_BITMAP_MAX_ROWS && out.cls_bits.size() + (span + 63u) / 64u < 0xFFFFFFFEull) {
         const size_t at = out.cls_bits.size();
         out.cls_bits.resize(at + (span + 63u) / 64u, 0ULL);
@@ -386,6 +387,8 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
         out.cls_desc[c * 4 + 1] = first;
         out.cls_desc[c * 4 + 2] = span;
         out.cls_desc[c * 4 + 3] = (uint32_t)at + 1u;
+      } else {
+        out.all_wide_have_bitmaps = false;
       }
     }
   }

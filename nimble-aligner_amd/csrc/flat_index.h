@@ -154,6 +154,7 @@ struct FlatIndex {
   std::vector<uint32_t> cls_desc;    // 4 x u32 per class
   std::vector<uint64_t> cls_bits;    // row bitmaps of the classes wider than the mask form (cls_desc words 1..3)
   bool all_classes_local = true;     // every static class has the mask form
+  bool all_wide_have_bitmaps = true; // every static class outside the mask form has a row bitmap in cls_bits
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };
 

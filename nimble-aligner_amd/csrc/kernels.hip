@@ -291,6 +291,14 @@ struct Lane {
   uint32_t fbase, min_len, min_col;
   bool all_mask;
   bool keep_list;  // some class of the index is not local: keep the visited colours for the general path
+  // ... unless the first visited class spans at most WIDE_ROWS rows: then the intersection is folded during the walk into
+  // a register window of that many rows starting at the class's first row (allele families of up to ~100 alleles: every
+  // class of a gene lies inside), and neither a colour list nor a pass over it is needed
+  bool window_ok;
+  bool use_window;  // the index allows it (every wide class has a row bitmap)
+  uint32_t wbase;
+  uint64_t wacc[4];
+  const uint64_t *cls_bits;
   uint32_t probes, nodes;
   uint64_t entries;
   int want_counters;
@@ -501,6 +509,22 @@ __device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base
   return -delta < 64 ? (m >> (-delta)) : 0ULL;
 }
 
+constexpr uint32_t WIDE_ROWS = 256;
+// 64 rows of class d starting at row `row0`, as a bit mask.  Mask-form classes carry their bits in the descriptor;
+// a wider static class has a span bitmap in ix.cls_bits (descriptor: y = first row of the bitmap, a multiple of 64 at or
+// below the class's first row; z = rows spanned from there; w = word offset + 1), built with the index.
+__device__ __forceinline__ uint64_t class_rows64(const uint4 &d, const uint64_t *__restrict__ cls_bits, uint32_t row0) {
+  if (desc_is_mask(d)) return mask_in_window(d, row0);
+  if (row0 + 64u <= d.y || row0 >= d.y + d.z) return 0ULL;
+  const uint64_t *__restrict__ w = cls_bits + (d.w - 1u);
+  const uint32_t n_words = (d.z + 63u) >> 6;
+  if (row0 < d.y) return w[0] << (d.y - row0);  // the window starts before the class does (delta < 64 here)
+  const uint32_t off = row0 - d.y, q = off >> 6, sh = off & 63u;
+  uint64_t v = w[q] >> sh;
+  if (sh && q + 1u < n_words) v |= w[q + 1u] << (64u - sh);
+  return v;
+}
+
 // a visited node: counters, running mask intersection and, only when the index has non-local classes, the
 // colour list for the general path
 __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 &desc) {
@@ -517,11 +541,39 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 
     ln.min_len = l;
     ln.min_col = colour;
   }
+  const bool first_node = ln.walk_nodes == 0;
   ln.walk_nodes++;
   ln.acc &= mask_in_window(desc, ln.fbase);  // idempotent: repeated colours cost nothing
   if (ln.keep_list) {
     ln.all_mask = ln.all_mask && desc_is_mask(desc);
+    if (first_node) {
+      // the window starts at a multiple of 64 rows, like the class bitmaps: one window word = one bitmap word
+      ln.wbase = desc.y & ~63u;
+      const uint32_t end = desc_is_mask(desc) ? desc.y + 64u : desc.y + desc.z;  // one past the last row it can hold
+      ln.window_ok = ln.use_window && end - ln.wbase <= WIDE_ROWS;
+      ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = ~0ULL;
+    }
     if (ln.n_cols && colour == ln.last_col) return;
+    if (ln.window_ok) {
+      ln.last_col = colour;
+      ln.n_cols = 1;
+      if (desc_is_mask(desc)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ln.wacc[q] &= mask_in_window(desc, ln.wbase + 64u * (uint32_t)q);
+      } else {
+        // word k of the class bitmap = rows desc.y + 64 k (desc.y is a multiple of 64): no shifts, and a window word
+        // that is already empty is not loaded
+        const uint64_t *__restrict__ w = ln.cls_bits + (desc.w - 1u);
+        const uint32_t n_words = (desc.z + 63u) >> 6;
+        const int32_t k0 = ((int32_t)ln.wbase - (int32_t)desc.y) >> 6;  // bitmap word under window word 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int32_t k = k0 + q;
+          if (ln.wacc[q]) ln.wacc[q] &= (k >= 0 && (uint32_t)k < n_words) ? w[k] : 0ULL;
+        }
+      }
+      return;
+    }
     uint32_t j = ln.n_cols;
     ln.last_col = colour;
     if (j < LDS_COLS) {
@@ -699,21 +751,6 @@ struct IRes {
   uint32_t count;
   uint64_t hash;
 };
-// 64 rows of class d starting at row `row0`, as a bit mask.  Mask-form classes carry their bits in the descriptor;
-// a wider static class has a span bitmap in ix.cls_bits (descriptor: y = first row, z = rows spanned, w = word
-// offset + 1), built with the index.
-__device__ __forceinline__ uint64_t class_rows64(const uint4 &d, const uint64_t *__restrict__ cls_bits, uint32_t row0) {
-  if (desc_is_mask(d)) return mask_in_window(d, row0);
-  if (row0 + 64u <= d.y || row0 >= d.y + d.z) return 0ULL;
-  const uint64_t *__restrict__ w = cls_bits + (d.w - 1u);
-  const uint32_t n_words = (d.z + 63u) >> 6;
-  if (row0 < d.y) return w[0] << (d.y - row0);  // the window starts before the class does (delta < 64 here)
-  const uint32_t off = row0 - d.y, q = off >> 6, sh = off & 63u;
-  uint64_t v = w[q] >> sh;
-  if (sh && q + 1u < n_words) v |= w[q + 1u] << (64u - sh);
-  return v;
-}
-
 __device__ __noinline__ IRes intersect_general(const uint4 *cls_desc, const uint32_t *cls_off, const uint32_t *cls_ids,
                                                const uint64_t *cls_bits, const uint32_t *lc, const uint32_t *ws,
                                                uint32_t ws_lanes, uint32_t n_cols, uint32_t best, uint32_t bl,
@@ -817,6 +854,31 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
   mr.base = 0;
   mr.mask = 0;
   if (WIDE && !ln.all_mask) {
+    if (ln.window_ok) {
+      // the intersection was folded into the register window during the walk: rows wbase + 64 q + bit
+      uint32_t count = 0, first_id = 0, last_id = 0;
+      uint64_t gmask = 0;
+      uint64_t h = class_hash_init();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        for (uint64_t m = ln.wacc[q]; m; m &= m - 1) {
+          const uint32_t id = ln.wbase + 64u * (uint32_t)q + (uint32_t)__ffsll((long long)m) - 1u;
+          if (out) out[count] = id;
+          h = class_hash_step(h, id);
+          if (count == 0) first_id = id;
+          last_id = id;
+          if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
+          ++count;
+        }
+      hash = class_hash_final(h, count);
+      if (count && last_id - first_id < 64u) {  // the result fits the mask form: same rule as everywhere
+        hash = class_hash_mask(count, first_id, gmask);
+        mr.is_mask = true;
+        mr.base = first_id;
+        mr.mask = gmask;
+      }
+      return count;
+    }
     const IRes r = intersect_general(ix.cls_desc, ix.cls_off, ix.cls_ids, ix.cls_bits, ln.lc, ln.ws, ln.ws_lanes, ln.n_cols,
                                      ln.min_col, ln.min_len, out);
     hash = r.hash;
@@ -837,6 +899,22 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
   return count;
 }
 
+// number of rows in the register window (cheap: the class itself is only spelled out when somebody needs it)
+__device__ __forceinline__ uint32_t window_count(const Lane &ln) {
+  return (uint32_t)(__popcll(ln.wacc[0]) + __popcll(ln.wacc[1]) + __popcll(ln.wacc[2]) + __popcll(ln.wacc[3]));
+}
+// is interned class `id` (ascending ids in cls_ids, `count` of them) exactly the content of the register window?
+__device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const Lane &ln, uint32_t id, uint32_t count) {
+  const uint32_t *__restrict__ ids = ix.cls_ids + ix.cls_off[id];
+  for (uint32_t t = 0; t < count; ++t) {
+    const uint32_t off = ids[t] - ln.wbase;  // wraps far above WIDE_ROWS for a row below the window
+    const uint32_t q = off >> 6;
+    const uint64_t w = q == 0 ? ln.wacc[0] : (q == 1 ? ln.wacc[1] : (q == 2 ? ln.wacc[2] : ln.wacc[3]));  // (no scratch)
+    if (off >= WIDE_ROWS || !((w >> (off & 63u)) & 1ULL)) return false;
+  }
+  return true;  // `count` distinct rows, all in the window, and the window holds exactly `count`
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_align: walk + class + thresholds, one lane per read(-pair), persistent grid-stride blocks
 // ---------------------------------------------------------------------------------------------
@@ -846,8 +924,10 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
 // WIDE: the index has classes wider than the 64-row mask form (ix.all_local == 0): the visited colours are kept and
 // the intersection may go through intersect_general.  The other instantiation carries none of that code -- the
 // out-of-line call alone costs the walk registers around it.
+// (the instantiation for indexes with wide classes carries the register window and the general intersection: it gets
+// 80 registers, i.e. 6 waves per SIMD, instead of spilling at 64)
 template <bool PAIRED, bool COUNTERS, bool WIDE>
-__global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p,
+__global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   constexpr int want_counters = COUNTERS ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -869,6 +949,11 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
   ln.fbase = ln.min_len = ln.min_col = 0;
   ln.all_mask = true;
   ln.keep_list = WIDE;
+  ln.window_ok = false;
+  ln.use_window = WIDE && ix.all_bitmaps != 0;
+  ln.wbase = 0;
+  ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = 0;
+  ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
   constexpr int nm = PAIRED ? 2 : 1;
@@ -984,7 +1069,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
             uint32_t count;
             best_col = ln.min_col;
             best_len = ln.min_len;
-            count = finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
+            // the class is spelled out (hash, mask form) only when it is needed: a walk in the register window knows its
+            // size from four popcounts, and a result of the size of the smallest visited class IS that class
+            const bool windowed = WIDE && !ln.all_mask && ln.window_ok;
+            count = windowed ? window_count(ln) : finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
             // `score as f64 / len as f64 >= score_percent` (align.rs:968, filter/align.rs:16) as an exact
             // integer test: min_cov[len] is the smallest score whose IEEE quotient reaches score_percent
             if (p.discard_nonzero_mismatch && mis != 0) {
@@ -998,10 +1086,12 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
                   cls = best_col;  // the intersection is the smallest colour itself
                 } else {
                   // an intersection that is not one of the visited colours: find its canonical id in the
-                  // content-addressed class table (exact compare of the mask form); only a class never seen
-                  // before goes through the claim / verify kernels
+                  // content-addressed class table (exact compare: the mask form against the descriptor, a wider class
+                  // in the register window against the stored ids); only a class never seen before goes through the
+                  // claim / verify kernels
                   cls = CLS_PENDING;
-                  if (mres.is_mask) {
+                  if (windowed) finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
+                  if (mres.is_mask || windowed) {
                     const uint32_t tag = intern_tag(dhash);
                     uint64_t pos = dhash & ix.intern_mask;
                     for (;;) {
@@ -1010,7 +1100,12 @@ __global__ __launch_bounds__(ALIGN_BLOCK, NIMBLE_ALIGN_WAVES) void k_align(DevIn
                       const uint32_t id = (uint32_t)slot;
                       if ((uint32_t)(slot >> 32) == tag && id != INTERN_PENDING && id < ix.cls_cap) {
                         const uint4 d = ix.cls_desc[id];
-                        if (d.x == (count | CLS_MASK_FLAG) && d.y == mres.base && desc_mask(d) == mres.mask) {
+                        if (mres.is_mask) {
+                          if (d.x == (count | CLS_MASK_FLAG) && d.y == mres.base && desc_mask(d) == mres.mask) {
+                            cls = id;
+                            break;
+                          }
+                        } else if (d.x == count && window_equals_class(ix, ln, id, count)) {
                           cls = id;
                           break;
                         }
@@ -1756,7 +1851,9 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter
-  static int resident_cache[128] = {0};
+  const bool wide = ix.all_local == 0;
+  static int resident_cache2[2][128] = {{0}, {0}};
+  int *resident_cache = resident_cache2[wide ? 1 : 0];  // the two kinds of instantiation differ in registers
   int key = (int)(lds / 2048) & 127;
   if (resident_cache[key] == 0) {
     if (lds > 48 * 1024) {  // long reads: opt in to more dynamic LDS than the default limit
@@ -1766,14 +1863,13 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                             (const void *)k_align<false, false, true>, (const void *)k_align<false, false, false>};
       for (const void *f : all) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    resident_cache[key] = resident_blocks((const void *)k_align<true, true, true>, lds);
+    resident_cache[key] = resident_blocks(wide ? (const void *)k_align<true, true, true> : (const void *)k_align<true, true, false>, lds);
   }
   // grid_pct < 100 leaves block slots free on every CU: a persistent grid that fills the chip would keep the
   // kernels of another stream (RCCL's exchange) waiting until it ends
   uint64_t resident = (uint64_t)resident_cache[key] * (uint64_t)(grid_pct < 10 ? 10 : (grid_pct > 100 ? 100 : grid_pct)) / 100;
   if (resident < 1) resident = 1;
   uint32_t grid = (uint32_t)(tiles < resident ? tiles : resident);
-  const bool wide = ix.all_local == 0;
 #define NIMBLE_LAUNCH_ALIGN(P, C, W) hipLaunchKernelGGL((k_align<P, C, W>), dim3(grid), dim3(ALIGN_BLOCK), lds, s, ix, p, cb)
   if (cb.paired) {
     if (want_counters) { if (wide) NIMBLE_LAUNCH_ALIGN(true, true, true); else NIMBLE_LAUNCH_ALIGN(true, true, false); }

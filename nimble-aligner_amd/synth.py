@@ -251,3 +251,22 @@ def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 <<
     src = nondup[pick]
     out[dup[ok]] = out[src[ok]]
     return out
+
+
+def make_family_library(T, F, seed=5, divergence=0.01):
+    """T features = T // F gene families of F alleles each: a random root of 600..2400 bases and F - 1 copies with
+    substitutions at `divergence` -- the shape of an immune-gene library (hundreds of alleles per gene, the domain of the
+    reference's own fixtures, tests/test-sequences/libraries/basic.json).  Returns (names, sequences)."""
+    rng = np.random.default_rng(seed)
+    names, seqs = [], []
+    for fam in range(T // F):
+        length = int(rng.integers(600, 2401))
+        root = rng.integers(0, 4, size=length, dtype=np.uint8)
+        for k in range(F):
+            a = root.copy()
+            if k:
+                m = rng.random(length) < divergence
+                a[m] = (a[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
+            names.append("G%04d*%03d" % (fam, k))
+            seqs.append(ACGT[a].tobytes().decode())
+    return names, seqs

@@ -248,14 +248,18 @@ def test_wide_classes_general_intersection_path():
     assert st["dynamic_classes"] > 0  # intersections that are not k-mer colours were interned on the device
 
 
-def test_large_allele_families_bitmap_intersection():
-    """Families of 150 alleles at 1 % divergence (what an immune-gene library looks like): the classes of the shared
-    k-mers span hundreds of neighbouring rows, beyond the 64-row mask form; the device intersects their row bitmaps
-    word by word (intersect_general, bitmap form).  Table, per-read records and class contents against the oracle."""
-    rng = np.random.default_rng(23)
+@pytest.mark.parametrize("sizes,n_reads", [((150, 70, 150, 3), 8000), ((500, 100, 20), 3000)])
+def test_large_allele_families_bitmap_intersection(sizes, n_reads):
+    """Families of 20 to 500 alleles at 1 % divergence (what an immune-gene library looks like): the classes of the
+    shared k-mers span hundreds of neighbouring rows, beyond the 64-row mask form.  A walk whose first class spans at
+    most 256 rows folds the row bitmaps of the visited classes into a register window (families of 70 and 100 here, at
+    row offsets that are no multiples of 64); wider ones keep the visited colours and intersect the bitmaps word by word
+    afterwards (intersect_general: families of 150 and 500).  Table, per-read records and class contents against the
+    oracle."""
+    rng = np.random.default_rng(23 + len(sizes))
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     names, seqs = [], []
-    for fam, size in enumerate((150, 70, 150, 3)):
+    for fam, size in enumerate(sizes):
         length = int(rng.integers(500, 900))
         root = rng.integers(0, 4, size=length, dtype=np.uint8)
         for k in range(size):
@@ -265,9 +269,9 @@ def test_large_allele_families_bitmap_intersection():
                 a[m] = (a[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
             names.append("G%d*%03d" % (fam, k))
             seqs.append(acgt[a].tobytes().decode())
-    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=30, max_hits_to_report=400))
+    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=30, max_hits_to_report=1200))
     reads = []
-    for _ in range(8000):
+    for _ in range(n_reads):
         f = int(rng.integers(0, len(seqs)))
         st = int(rng.integers(0, len(seqs[f]) - 150))
         r = np.frombuffer(seqs[f][st:st + 150].encode(), dtype=np.uint8).copy()
