@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the hot path (score::call: pack -> align -> intern -> dedup -> count -> rows) on MI355X.
 
-Workload at N=1: BASELINE.json configs[2] -- 10 M synthetic 150 bp single-end reads against a 1 k-feature
-(2 k index rows) allele-family library with the basic.json alignment settings; reads are resident in HBM when
-the timed region starts.  A "step" is one complete score::call over the batch, ending with the sorted
-(callset -> count) rows on the host.  At N>1 every rank holds its own 10 M reads (weak scaling) and a step is
-partition -> all-to-all exchange by read key -> score::call per rank -> all-reduce of the count vector (RCCL).
+Default workload (every N): BASELINE.json configs[2] -- 10 M synthetic 150 bp single-end reads per GPU against a
+1 k-feature (2 k index rows) allele-family library with the basic.json alignment settings; reads are resident in HBM when
+the timed region starts.  A "step" is one complete score::call over one batch, ending with the sorted (callset -> count)
+rows on the host.  Successive steps take DIFFERENT read sets (--read-sets, default 3, rotated), so the class table, the
+host's coercion memo and the multi-GPU key agreement keep meeting new material as they do in production.  At N>1 every
+rank holds its own reads (weak scaling) and a step is partition -> all-to-all exchange by read key -> score::call per rank
+-> all-reduce of the count vector (RCCL).
 
-Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel
-(k_align, HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box's host cores).
+Other workloads (--workload): `configs4` = BASELINE.json configs[4], 80 M reads in total split over the ranks against a
+5 k-feature library; `configs3` = configs[3], paired-end 2x150 with the mismatch.json settings; `families100` = a library of
+gene families of 100 alleles at 1 % divergence (the shape of the reference's own MHC fixtures), same reads recipe.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel (k_align,
+HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box's host cores), plus `step_ms` (min / median
+/ max over the timed steps) and, at N=1, `e2e_fastq_reads_per_s` / `e2e_fastq_gz_reads_per_s`: the whole FASTQ pipeline
+(lib/nimble: parse, H2D, call, TSV) on a bounded file, outside the timed value.
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,14 +34,70 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
 
+WORKLOADS = {
+    "configs2": dict(features=1000, family=4, paired=False, reads=10_000_000, total=False,
+                     text="BASELINE.json configs[2]: %(n)d x 150bp single-end reads per GPU vs %(T)d-feature library "
+                          "(%(rows)d index rows), basic.json settings (score_percent 0.33, score_threshold 50, "
+                          "num_mismatches 0), unstranded"),
+    "configs3": dict(features=1000, family=4, paired=True, reads=5_000_000, total=False,
+                     text="BASELINE.json configs[3]: %(n)d paired-end 2x150bp read pairs per GPU vs %(T)d-feature library "
+                          "(%(rows)d index rows), mismatch.json settings (score_percent 0.08, score_threshold 12, "
+                          "num_mismatches 2), unstranded"),
+    "configs4": dict(features=5000, family=4, paired=False, reads=80_000_000, total=True,
+                     text="BASELINE.json configs[4]: 80 M x 150bp single-end reads in total, %(n)d per GPU, vs %(T)d-feature "
+                          "library (%(rows)d index rows), basic.json settings, unstranded"),
+    "families100": dict(features=1000, family=100, paired=False, reads=4_000_000, total=False,
+                        text="allele families of 100 (not a BASELINE.json config): %(n)d x 150bp single-end reads per GPU vs "
+                             "%(T)d features = %(fam)d gene families of 100 alleles at 1 %% divergence (%(rows)d index rows), "
+                             "basic.json settings, unstranded"),
+}
+
+
+def e2e_fastq(names, seqs, reads_np, n_plain, n_gz):
+    """The FASTQ pipeline end to end through the argv-compatible CLI (parse + H2D + call + TSV), page cache warm."""
+    synth = importlib.import_module("nimble-aligner_amd.synth")
+    exe = os.path.join(ROOT, "nimble-aligner_amd", "lib", "nimble")
+    out = {}
+    d = tempfile.mkdtemp(prefix="nimble_e2e_", dir="/tmp")
+    try:
+        libp = os.path.join(d, "lib.json")
+        synth.write_library(libp, names, seqs)
+        fq = os.path.join(d, "reads.fastq")
+        synth.write_fastq_fast(fq, reads_np[:n_plain])
+        fz = os.path.join(d, "reads_gz.fastq")
+        synth.write_fastq_fast(fz, reads_np[:n_gz])
+        subprocess.run(["gzip", "-1", "-f", fz], check=True)
+        for tag, path, n in (("warm", fq, n_plain), ("e2e_fastq_reads_per_s", fq, n_plain),
+                             ("e2e_fastq_gz_reads_per_s", fz + ".gz", n_gz)):
+            env = dict(os.environ, NIMBLE_HOST_TIMING="1")
+            t0 = time.perf_counter()
+            cp = subprocess.run([exe, "-r", libp, "-o", os.path.join(d, tag + ".tsv"), "-i", path, "-f", "unstranded"],
+                                capture_output=True, text=True, env=env)
+            wall = time.perf_counter() - t0
+            if cp.returncode != 0:
+                raise RuntimeError(cp.stderr[-500:])
+            pipe = [l for l in cp.stderr.splitlines() if "fastq pipeline" in l]
+            secs = float(pipe[-1].split(")")[1].split("s,")[0]) if pipe else wall
+            if tag != "warm":
+                out[tag] = n / secs
+                out[tag.replace("reads_per_s", "wall_s")] = wall
+        out["e2e_note"] = ("lib/nimble on %d (plain) / %d (.gz, gzip -1) of the bench reads written as FASTQ: reads/s of the "
+                           "pipeline itself (mapped file -> parse -> pinned batches -> H2D -> one call -> TSV); the wall "
+                           "figure adds process start, index build and HIP initialisation" % (n_plain, n_gz))
+    finally:
+        subprocess.run(["rm", "-rf", d])
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
-    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs2")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own size)")
+    ap.add_argument("--features", type=int, default=0, help="library features (0 = the workload's own size)")
+    ap.add_argument("--read-sets", type=int, default=3, help="distinct read sets rotated through the steps")
     ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
                     help="calls in flight at N=1: 2 = step i+1 runs on the GPU while the host finishes step i")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -44,6 +111,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000,
+                    help="reads of the end-to-end FASTQ run at N=1 (0 = skip); the .gz run takes a quarter of them")
     args = ap.parse_args()
 
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run
@@ -77,32 +146,47 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
+    wl = WORKLOADS[args.workload]
     L = 150
-    n = args.reads
-    names, seqs = synth.make_library(args.features)
+    T = args.features or wl["features"]
+    n = args.reads or (wl["reads"] // world if wl["total"] else wl["reads"])
+    paired = wl["paired"]
+    if paired and sharded:
+        raise SystemExit("bench.py: the paired-end workload is a single-GPU configuration (BASELINE.json configs[3])")
+    if wl["family"] > 4:
+        names, seqs = synth.make_family_library(T, wl["family"])
+    else:
+        names, seqs = synth.make_library(T)
     lib_obj = synth.library_json(names, seqs)
+    if args.workload == "configs3":  # mismatch.json settings with num_mismatches 2 (tests/mismatch.rs:45, basic-cases.rs:119)
+        lib_obj[0].update(score_percent=0.08, score_threshold=12, num_mismatches=2)
     lib = nim.Library(text=json.dumps(lib_obj), strand_filter="unstranded").build_index(local_rank)
     ctx = lib.device_context()
-    reads = synth.make_reads_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * rank, device=str(device))
+    n_sets = max(1, args.read_sets)
+    if paired:
+        sets = []
+        for k in range(n_sets):
+            a, b = synth.make_reads(seqs, n, paired=True, seed=synth.READ_SEED + 7919 * rank + 104729 * k)
+            sets.append((torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)))
+    else:
+        sets = [(synth.make_reads_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * rank + 104729 * k, device=str(device)),
+                 None) for k in range(n_sets)]
     torch.cuda.synchronize()
-
-    def compute(a, b=None):
-        torch.cuda.current_stream().synchronize()  # reads produced on torch's stream; the call runs on its own
-        return lib.score_call(a, None, n=a.shape[0], fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
-
     reducer = nd.TableReducer(device) if sharded else None
 
-    def step():
+    def step(k=0):
         """One score::call: ends with the sorted rows materialised on the host (C++ result object)."""
+        r1, r2 = sets[k % n_sets]
         if sharded:
-            # pack -> route by key hash (device kernels) -> all-to-all of the records -> unpack -> finish per rank
+            # pack -> route by key hash (device kernels) -> all-to-all of the records -> finish per rank
             # -> all-reduce of the counts over the agreed callset table
-            return nd.sharded_step(lib, reads, None, n, L, device, reducer)
-        return lib.score_call_raw(reads, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+            return nd.sharded_step(lib, r1, None, n, L, device, reducer)
+        return lib.score_call_raw(r1, r2, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
-    # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count
+    # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count (read set 0; the
+    # sets are draws of one recipe and agree to a fraction of a percent)
     ctx.set_counters(True)
-    rows = step()
+    rows = step(0)
     ctx.n = n
     counters = ctx.counters()   # multi-GPU: of the shard this rank received (statistically the same reads)
     ctx.set_counters(False)
@@ -112,8 +196,9 @@ def main():
     for c in ctxs:
         c.set_counters(False)  # the work counters cost ~30 % of k_align; collected once, above
 
-    def begin(slot):
-        lib.score_call_begin(slot, reads, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+    def begin(slot, k):
+        r1, r2 = sets[k % n_sets]
+        lib.score_call_begin(slot, r1, r2, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     def end(slot):
         r = lib.score_call_end(slot, raw=True)
@@ -122,11 +207,11 @@ def main():
         return r
 
     stage = {k: 0.0 for k in ("pack", "align", "intern", "dedup", "count", "total")}
-    for _ in range(args.warmup):
-        rows = step()
+    for w in range(args.warmup):
+        rows = step(w)
     if depth > 1:
         for s in range(depth):  # the second slot allocates its buffers on first use
-            begin(s)
+            begin(s, s)
         for s in range(depth):
             end(s)
     pipe = None
@@ -134,37 +219,44 @@ def main():
         pipe = (nd.LocalAlignPipeline if args.form == "local" else nd.ShardedPipeline)(lib, device, reducer)
         for s_ in range(4 if args.form == "local" else 3):
             lib.device_context(s_).set_counters(False)
-        for _ in range(max(args.warmup, 3)):   # allocates the other call slots and the utility context
-            pipe.submit(reads, None, n, L)
+        for w in range(max(args.warmup, 3)):   # allocates the other call slots and the utility context
+            pipe.submit(sets[w % n_sets][0], None, n, L)
         for r in pipe.flush():
             rows = r
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     stage = {k: 0.0 for k in stage}
+    marks = []  # host time at which each step's rows were in hand
     t0 = time.perf_counter()
     if sharded and not args.no_pipeline:
         # software-pipelined multi-GPU steps: K submits + the drain all end inside the timed region
-        for _ in range(args.steps):
-            r = pipe.submit(reads, None, n, L)
-            rows = r if r is not None else rows
+        for i in range(args.steps):
+            r = pipe.submit(sets[i % n_sets][0], None, n, L)
+            if r is not None:
+                rows = r
+                marks.append(time.perf_counter())
         for r in pipe.flush():
             rows = r
+            marks.append(time.perf_counter())
         for k, v in ctx.timing().items():
             stage[k] += v * args.steps
     elif depth == 1:
-        for _ in range(args.steps):
-            rows = step()
+        for i in range(args.steps):
+            rows = step(i)
+            marks.append(time.perf_counter())
             for k, v in ctx.timing().items():
                 stage[k] += v
     else:
         # every step is a complete score::call (begin + end); two are in flight, all K end inside the timed region
         for i in range(args.steps):
-            begin(i % 2)
+            begin(i % 2, i)
             if i:
                 rows = end((i - 1) % 2)
+                marks.append(time.perf_counter())
         if args.steps:
             rows = end((args.steps - 1) % 2)
+            marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,29 +267,33 @@ def main():
         elapsed = float(t.item())
     steps = max(args.steps, 1)
     stage = {k: v / steps for k, v in stage.items()}
-    total_reads = n * world * steps
-    value = total_reads / elapsed
+    units = n * world * steps
+    value = units / elapsed
     # device time per call: the event span of one call, unless calls overlap on the device (then the step time)
     device_ms = stage["total"] if (depth == 1 and not sharded) else 1000.0 * elapsed / steps
+    # per-step host intervals (completion to completion; with calls in flight the first one carries the fill)
+    per = [1000.0 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]
+    steady = per[1:] if len(per) > 2 else per
 
+    fam = T // wl["family"]
     out = {
         "metric": "reads/sec aligned (whole job), counts bit-exact vs the CPU path",
-        "value": value,
+        "value": value * (2 if paired else 1),
         "unit": "reads/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if not wl["total"] else "strong",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE.json configs[2]: %d x %dbp single-end reads per GPU vs %d-feature library "
-                        "(%d index rows), basic.json settings (score_percent 0.33, score_threshold 50, "
-                        "num_mismatches 0), unstranded" % (n, L, args.features, 2 * args.features),
-            "reads_per_gpu": n, "read_len": L, "features": args.features,
+            "workload": wl["text"] % dict(n=n, T=T, rows=2 * T, fam=fam),
+            "workload_id": args.workload,
+            "reads_per_gpu": n, "read_len": L, "features": T, "paired": paired,
+            "read_sets_rotated": n_sets,
             "parallelism": (("1 process/GPU; reads aligned where they are, keys to their owner by hash (all-to-all), "
                              "verdict bytes back (all-to-all) + count all-reduce (RCCL); key exchange of step i "
                              "beside its own alignment" if args.form == "local" and not args.no_pipeline else
@@ -207,10 +303,13 @@ def main():
             "rows": len(rows) if not sharded else len(reducer.rows(*rows)),
             "calls_in_flight": depth,
         },
+        "step_ms": {"min": min(steady), "median": statistics.median(steady), "max": max(steady),
+                    "note": "host interval between successive completed steps (the first, which carries the pipeline fill, "
+                            "left out)"} if steady else None,
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "stage_note": ("per call, HIP events; with calls in flight the dedup / count / compaction of call i run on a "
-                       "side stream beside the pack of call i+1, so pack and dedup read longer than alone "
-                       "(0.37 / 0.53 ms) and 'total' is the latency of one call, not the time per call"),
+                       "side stream beside the pack of call i+1, so pack and dedup read longer than alone and 'total' is "
+                       "the latency of one call, not the time per call"),
         "device_reads_per_s": n / (device_ms / 1000.0) if device_ms > 0 else None,
     }
 
@@ -218,18 +317,23 @@ def main():
         # ---- roofline of the dominant kernel (k_align): algorithmic bytes of one launch / its duration
         P, U, E = counters["probes"], counters["nodes"], counters["class_entries"]
         hit = counters["seeded"]
-        key_bytes = 8 * ((L + 31) // 32)
+        nm = 2 if paired else 1
+        key_bytes = 8 * ((nm * L + 31) // 32)
         n_call = int(counters["reads"]) if sharded else n   # reads of the launch the counters describe
-        align_bytes = n_call * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n_call
-        pipe_bytes = n_call * L + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n_call
+        align_bytes = n_call * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n_call * nm
+        pipe_bytes = n_call * L * nm + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n_call * nm
         align_s = stage["align"] / 1000.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reads") == n and tj.get("features") == args.features and not sharded:
+                if (tj.get("reads") == n and tj.get("features") == T and tj.get("workload", "configs2") == args.workload
+                        and not sharded):
                     traffic = tj.get("k_align_hbm_bytes_per_launch")
+                    traffic_source = ("replayed from %s (rocprofv3 --pmc pass of this command at this size: %s); PMC "
+                                      "counters cannot be collected inside a timed run" %
+                                      ("profiles/traffic_latest.json", tj.get("source", "see profiles/")))
             except Exception:
                 traffic = None
         # measured device stream copy on this box: read + write of 1 GiB, best of 5
@@ -254,6 +358,7 @@ def main():
             "unit": "GB/s",
             "frac": align_bytes / align_s / 1e9 / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": align_bytes,
             "kernel_ms": stage["align"],
             "bytes_per_read": align_bytes / max(n_call, 1),
@@ -268,7 +373,9 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             from oracle import oracle as ora
             S = min(args.cpu_sample, n)
-            sample = reads[:S].cpu().numpy()
+            r1, r2 = sets[0]
+            sample = r1[:S].cpu().numpy()
+            sample2 = r2[:S].cpu().numpy() if paired else None
             cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
             ref = ora.Reference.from_columns(lib_obj[1]["headers"], cols, "")
             cfg = ora.config_from_json(lib_obj[0], len(names), "unstranded")
@@ -276,25 +383,37 @@ def main():
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
             offs = synth.fixed_offsets(S, L)
             t1 = time.perf_counter()
-            ores = ora.call(oidx, ref, cfg, sample.reshape(-1), offs, n_threads=threads)
+            ores = ora.call(oidx, ref, cfg, sample.reshape(-1), offs, None if not paired else sample2.reshape(-1),
+                            None if not paired else offs, n_threads=threads)
             cpu_s = time.perf_counter() - t1
             S1 = min(S, 1_000_000)
             t1 = time.perf_counter()
-            ora.call(oidx, ref, cfg, sample[:S1].reshape(-1), synth.fixed_offsets(S1, L), n_threads=1)
+            ora.call(oidx, ref, cfg, sample[:S1].reshape(-1), synth.fixed_offsets(S1, L),
+                     None if not paired else sample2[:S1].reshape(-1),
+                     None if not paired else synth.fixed_offsets(S1, L), n_threads=1)
             cpu1_s = time.perf_counter() - t1
             # parity on the sample: the GPU table must equal the oracle's table
-            got = lib.score_call(reads[:S].contiguous(), None, n=S, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+            got = lib.score_call(r1[:S].contiguous(), None if not paired else r2[:S].contiguous(), n=S, fixed_len=L,
+                                 max_len=L, mem=nim.MEM_DEVICE)
             parity = [(f, c) for f, c in got] == [(f, c) for f, c in ores.rows]
             if not parity:
                 raise SystemExit("bench.py: GPU table differs from the CPU oracle on the sample")
+            per_unit = 2 if paired else 1
             out["cpu_baseline"] = {
-                "value": S / cpu_s, "unit": "reads/s", "cores": threads, "kind": "port",
-                "sample": "first %d of the %d reads, oracle/libnimble_oracle.so, %d threads (hash-partitioned by key); "
-                          "index build and read generation excluded" % (S, n, threads),
-                "single_thread_value": S1 / cpu1_s,
+                "value": per_unit * S / cpu_s, "unit": "reads/s", "cores": threads, "kind": "port",
+                "sample": "first %d of the %d reads(-pairs) of read set 0, oracle/libnimble_oracle.so, %d threads "
+                          "(hash-partitioned by key); index build and read generation excluded" % (S, n, threads),
+                "single_thread_value": per_unit * S1 / cpu1_s,
                 "parity_on_sample": "bit-exact table (%d rows)" % len(got),
             }
-            out["speedup_vs_cpu_baseline"] = value / (S / cpu_s)
+            out["speedup_vs_cpu_baseline"] = out["value"] / (per_unit * S / cpu_s)
+        # ---- end to end from a FASTQ file (SURVEY 8(d) figure B), outside the timed value
+        if args.e2e_reads > 0 and world == 1 and not paired and not args.force_sharded:
+            try:
+                m = min(args.e2e_reads, n)
+                out.update(e2e_fastq(names, seqs, sets[0][0][:m].cpu().numpy(), m, max(m // 4, 1)))
+            except Exception as ex:  # the bench line must not die with the side measurement
+                out["e2e_error"] = str(ex)[:300]
     if rank == 0 and getattr(nd, "_TIMING", None):
         k = max(nd._TIMING.get("steps", 1), 1)
         out["sharded_phase_ms"] = {a: round(b / k, 3) for a, b in nd._TIMING.items() if a != "steps"}

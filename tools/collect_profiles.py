@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -34,6 +34,7 @@ vals = dict(re.findall(r"^\s+(\S+)\s+avg/dispatch\s+(\S+)", blk.group(1), re.M))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     fetch, write = float(vals["FETCH_SIZE"]) * 1024, float(vals["WRITE_SIZE"]) * 1024
     t = {"reads": bench["config"]["reads_per_gpu"], "features": bench["config"]["features"],
+         "workload": bench["config"].get("workload_id", "configs2"),
          "k_align_hbm_bytes_per_launch": 2 * fetch + write,
          "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
          "correction": "2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE; memory-side of L2, "
