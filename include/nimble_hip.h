@@ -286,6 +286,45 @@ int nimble_ctx_synchronize(nimble_ctx *);
  * `counts` is DEVICE memory (int64), written on the context's stream, ready for an RCCL all-reduce. */
 int nimble_histogram_dense_se(nimble_ctx *, int64_t *counts_dev, uint32_t n_classes);
 
+/* ---- single-node multi-GPU without torch or MPI: one process, one rank (= one host thread) per device.
+ *      Replaces nothing in the reference (it has no multi-device path); it is what BASELINE.json's north star asks
+ *      of this build: reads shard by record, the ranks exchange routed records all-to-all and sum per-callset count
+ *      vectors with RCCL over xGMI (SURVEY.md 8(b) `counts_allreduce`, 8(e)).
+ *
+ *      devices[n]: the HIP ordinal of each rank.  Distinct ordinals give RCCL communicators (ncclCommInitAll) and
+ *      every collective below is an RCCL call on the rank's stream.  The SAME ordinal n times puts n ranks on one
+ *      GPU -- the rehearsal and test configuration of a one-GPU box -- and the same entry points move the data with
+ *      device copies instead (nimble_comm_uses_rccl tells which).
+ *
+ *      Every entry that takes (comm, rank) is COLLECTIVE: each rank calls it once, from its own thread, in the same
+ *      order; a rank's failure is reported to all of them (nobody is left waiting). */
+typedef struct nimble_comm nimble_comm;
+int nimble_comm_create(const int *devices, int n, nimble_comm **out);
+void nimble_comm_free(nimble_comm *);
+int nimble_comm_size(const nimble_comm *);
+int nimble_comm_uses_rccl(const nimble_comm *);
+/* In-place sum over the ranks of an int64 vector (counts are i32 in the reference, src/align.rs:186; int64 on the
+ * wire): device memory on the rank's stream, or host memory (staged through the device, complete on return). */
+int nimble_counts_allreduce(nimble_comm *, int rank, int64_t *counts_dev, uint64_t len, void *stream);
+int nimble_counts_allreduce_host(nimble_comm *, int rank, int64_t *counts, uint64_t len);
+/* All-to-all of routed records (nimble_route_records): `send` holds this rank's records grouped by destination,
+ * send_counts[size] records for each; `recv` (device, room for recv_cap records) receives every rank's share for this
+ * rank, in source order; *n_recv = how many.  Fails with NIMBLE_E_OVERFLOW on every rank, nothing moved, if somebody's
+ * recv buffer is too small. */
+int nimble_records_alltoall(nimble_comm *, int rank, const uint64_t *send, const uint64_t *send_counts,
+                            uint32_t rec_words, uint64_t *recv, uint64_t recv_cap, uint64_t *n_recv, void *stream);
+/* One score::call whose reads are spread over the ranks (the dedup scope is the whole call, so equal read keys must
+ * meet on one rank): begin names the rank's context (its index lives on the rank's device); every append is one
+ * round -- each rank packs its batch where it is, routes it by key hash, the records travel all-to-all and each rank
+ * keeps what it owns (a rank without reads in a round appends n = 0); end runs the rest of the call over the records the
+ * rank owns.  The context's getters then behave as after nimble_call_records, and the ranks' histograms add up to the
+ * single-GPU one. */
+int nimble_sharded_begin(nimble_comm *, int rank, nimble_ctx *, const nimble_align_params *, int paired,
+                         uint32_t max_len);
+int nimble_sharded_append(nimble_comm *, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                          const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
+int nimble_sharded_end(nimble_comm *, int rank, uint64_t *n_owned);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,6 +138,11 @@ const char *nimble_rows_get(const nimble_rows *, uint64_t i, int32_t *count);
 /* fastq::process: libraries must have their index built */
 int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, nimble_library *const *libs,
                          const char *const *outputs);
+/* The same pipeline over several GPUs of one node, one rank (host thread) per entry of devices[] (an ordinal may repeat:
+ * ranks sharing a GPU), reads exchanged by key and counts summed over RCCL -- include/nimble_hip.h nimble_comm_*.  The
+ * library's index is built on every rank's device for the run. */
+int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble_library *lib, const int *devices,
+                                 int n_devices, const char *output);
 int nimble_write_to_tsv(const nimble_rows *, const char *output_path);
 
 /* host-only pieces, exposed for CPU tests of the host logic */

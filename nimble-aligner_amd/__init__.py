@@ -91,7 +91,9 @@ HIP_SYMBOLS = [
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
-    "nimble_call_records",
+    "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl",
+    "nimble_counts_allreduce", "nimble_counts_allreduce_host", "nimble_records_alltoall", "nimble_sharded_begin",
+    "nimble_sharded_append", "nimble_sharded_end",
 ]
 
 
@@ -149,6 +151,17 @@ def hip_lib():
         L.nimble_call_records.argtypes = [vp, C.POINTER(AlignParams), vp, u64, u32, i32]
         L.nimble_ctx_stream.argtypes = [vp]
         L.nimble_ctx_stream.restype = vp
+        L.nimble_comm_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+        L.nimble_comm_free.argtypes = [vp]
+        L.nimble_comm_free.restype = None
+        L.nimble_comm_size.argtypes = [vp]
+        L.nimble_comm_uses_rccl.argtypes = [vp]
+        L.nimble_counts_allreduce.argtypes = [vp, i32, vp, u64, vp]
+        L.nimble_counts_allreduce_host.argtypes = [vp, i32, vp, u64]
+        L.nimble_records_alltoall.argtypes = [vp, i32, vp, vp, u32, vp, u64, C.POINTER(u64), vp]
+        L.nimble_sharded_begin.argtypes = [vp, i32, vp, C.POINTER(AlignParams), i32, u32]
+        L.nimble_sharded_append.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, i32]
+        L.nimble_sharded_end.argtypes = [vp, i32, C.POINTER(u64)]
         _hip = L
     return _hip
 
@@ -457,6 +470,7 @@ HOST_SYMBOLS = [
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
     "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
+    "nimble_fastq_process_sharded",
 ]
 
 
@@ -542,6 +556,7 @@ def host_lib():
         L.nimble_rows_get.argtypes = [vp, u64, C.POINTER(C.c_int32)]
         L.nimble_rows_get.restype = cp
         L.nimble_fastq_process.argtypes = [i32, pp, i32, C.POINTER(vp), pp]
+        L.nimble_fastq_process_sharded.argtypes = [i32, pp, vp, C.POINTER(i32), i32, cp]
         L.nimble_write_to_tsv.argtypes = [vp, cp]
         L.nimble_host_coerce.argtypes = [vp, i32, vp, i32, i32, vp, i32, cp, i32]
         L.nimble_host_natural_lexical_cmp.argtypes = [cp, cp]
@@ -961,6 +976,14 @@ def fastq_process(input_files, libraries, output_paths):
     arr = (C.c_void_p * len(libraries))(*[l.h for l in libraries])
     _hcheck(host_lib().nimble_fastq_process(len(input_files), _cstrs(input_files), len(libraries), arr,
                                             _cstrs(output_paths)))
+
+
+def fastq_process_sharded(input_files, library, devices, output_path):
+    """process::fastq::process over several ranks (one per entry of `devices`; an ordinal may repeat)."""
+    L = host_lib()
+    ins = _cstrs(input_files)
+    dev = (C.c_int * len(devices))(*devices)
+    _hcheck(L.nimble_fastq_process_sharded(len(input_files), ins, library.h, dev, len(devices), output_path.encode()))
 
 
 def natural_lexical_cmp(a, b):

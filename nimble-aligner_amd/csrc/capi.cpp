@@ -4,8 +4,10 @@
 //   pack -> align -> intern (claim / verify rounds) -> dedup -> count
 // There is no CPU path here: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -939,7 +941,10 @@ static int stage_inputs(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off
     }
     int rc = c->b_in[m].ensure(std::max<uint64_t>(bytes, 16), &c->bytes);
     if (rc) return rc;
-    if (bytes) HIPCHK(hipMemcpyAsync(c->b_in[m].p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    // (offsets are absolute: a slice of a larger batch is the same buffer with a later offsets pointer, and only the
+    // bytes its reads cover travel)
+    const uint64_t lo = off && n ? off[0] : 0;
+    if (bytes > lo) HIPCHK(hipMemcpyAsync(c->b_in[m].as<uint8_t>() + lo, src + lo, bytes - lo, hipMemcpyHostToDevice, c->stream));
     c->in_r[m] = c->b_in[m].as<uint8_t>();
     if (off) {
       rc = c->b_in_off[m].ensure((n + 1) * 8, &c->bytes);
@@ -1747,6 +1752,319 @@ int nimble_call_timing(nimble_ctx *c, float ms[6]) {
   for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
   HIPCHK(hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
   return NIMBLE_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================================
+// Single-node multi-GPU: one process, one rank (host thread) per device.  The ranks of a nimble_comm exchange routed
+// records all-to-all and sum count vectors with RCCL over xGMI; no torch, no MPI.  (SURVEY 8(b) `counts_allreduce`,
+// 8(e): reads shard by record, equal keys must meet on one rank because the dedup scope is the whole call.)
+// =================================================================================================================
+struct nimble_comm {
+  int n = 0;
+  std::vector<int> devices;
+  bool rccl = false;                 // distinct devices: RCCL communicators; repeated devices: device copies (one GPU)
+  std::vector<ncclComm_t> comms;
+  // what the ranks tell each other between the barriers of a collective call (all in this process's memory)
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<uint64_t> counts;            // [src][dst] records of the running all-to-all
+  std::vector<const uint64_t *> send_ptr;  // [src]
+  std::vector<void *> vec_ptr;             // [rank] host vectors of the running all-reduce
+  std::vector<int> status;                 // [rank] a rank's failure is everybody's
+  // per rank: the sharded call (nimble_sharded_*)
+  struct Shard {
+    nimble_ctx *ctx = nullptr;
+    nimble_align_params prm{};
+    int paired = 0;
+    uint32_t max_len = 0, rec_words = 0;
+    DevBuf send, acc, vec;
+    uint64_t n_acc = 0, acc_cap = 0;
+    bool open = false;
+  };
+  std::vector<Shard> shard;
+  void barrier() {
+    std::unique_lock<std::mutex> lock(mu);
+    const uint64_t gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return generation != gen; });
+    }
+  }
+  // every rank reports its status; all of them leave with the worst one
+  int agree(int rank, int rc) {
+    status[rank] = rc;
+    barrier();
+    int worst = NIMBLE_OK;
+    for (int r = 0; r < n; ++r)
+      if (status[r] != NIMBLE_OK) worst = status[r];
+    barrier();
+    return worst;
+  }
+};
+
+#define NCCLCHK(expr)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) return fail(NIMBLE_E_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+
+extern "C" {
+
+int nimble_comm_create(const int *devices, int n, nimble_comm **out) {
+  if (!devices || !out || n < 1 || n > 256) return fail(NIMBLE_E_INVALID, "nimble_comm_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NIMBLE_E_NO_DEVICE, "nimble_comm_create: no HIP device (this library has no CPU path)");
+  std::vector<int> sorted(devices, devices + n);
+  for (int d : sorted)
+    if (d < 0 || d >= ndev) return fail(NIMBLE_E_INVALID, "nimble_comm_create: bad device ordinal");
+  std::sort(sorted.begin(), sorted.end());
+  const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+  if (!distinct && sorted.front() != sorted.back())
+    return fail(NIMBLE_E_INVALID, "nimble_comm_create: ranks must be on distinct devices, or all on one");
+  nimble_comm *c = new (std::nothrow) nimble_comm();
+  if (!c) return fail(NIMBLE_E_NOMEM, "out of memory");
+  c->n = n;
+  c->devices.assign(devices, devices + n);
+  c->rccl = distinct;
+  c->counts.assign((size_t)n * n, 0);
+  c->send_ptr.assign(n, nullptr);
+  c->vec_ptr.assign(n, nullptr);
+  c->status.assign(n, NIMBLE_OK);
+  c->shard.resize(n);
+  if (c->rccl) {
+    c->comms.resize(n);
+    ncclResult_t r = ncclCommInitAll(c->comms.data(), n, c->devices.data());
+    if (r != ncclSuccess) {
+      delete c;
+      return fail(NIMBLE_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+    }
+  }
+  *out = c;
+  return NIMBLE_OK;
+}
+
+void nimble_comm_free(nimble_comm *c) {
+  if (!c) return;
+  for (int r = 0; r < c->n; ++r) {
+    (void)hipSetDevice(c->devices[r]);
+    c->shard[r].send.release();
+    c->shard[r].acc.release();
+    c->shard[r].vec.release();
+  }
+  for (ncclComm_t m : c->comms) (void)ncclCommDestroy(m);
+  delete c;
+}
+
+int nimble_comm_size(const nimble_comm *c) { return c ? c->n : 0; }
+int nimble_comm_uses_rccl(const nimble_comm *c) { return c && c->rccl ? 1 : 0; }
+
+int nimble_counts_allreduce(nimble_comm *c, int rank, int64_t *counts_dev, uint64_t len, void *stream) {
+  if (!c || rank < 0 || rank >= c->n || (len && !counts_dev)) return fail(NIMBLE_E_INVALID, "nimble_counts_allreduce: bad argument");
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  hipStream_t s = (hipStream_t)stream;
+  if (c->rccl) {
+    if (len) NCCLCHK(ncclAllReduce(counts_dev, counts_dev, len, ncclInt64, ncclSum, c->comms[rank], s));
+    return NIMBLE_OK;
+  }
+  // ranks that share one device: every rank's vector through the host, summed by each rank for itself
+  std::vector<int64_t> mine(len), sum(len, 0);
+  int rc = NIMBLE_OK;
+  if (len && hipMemcpyAsync(mine.data(), counts_dev, len * 8, hipMemcpyDeviceToHost, s) != hipSuccess) rc = NIMBLE_E_HIP;
+  if (rc == NIMBLE_OK && hipStreamSynchronize(s) != hipSuccess) rc = NIMBLE_E_HIP;
+  c->vec_ptr[rank] = mine.data();
+  rc = c->agree(rank, rc);
+  if (rc == NIMBLE_OK)
+    for (int r = 0; r < c->n; ++r) {
+      const int64_t *v = static_cast<const int64_t *>(c->vec_ptr[r]);
+      for (uint64_t i = 0; i < len; ++i) sum[i] += v[i];
+    }
+  c->barrier();  // nobody's vector goes away before everybody has read it
+  if (rc != NIMBLE_OK) return fail(rc, "nimble_counts_allreduce: a rank failed");
+  if (len) HIPCHK(hipMemcpyAsync(counts_dev, sum.data(), len * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NIMBLE_OK;
+}
+
+int nimble_counts_allreduce_host(nimble_comm *c, int rank, int64_t *counts, uint64_t len) {
+  if (!c || rank < 0 || rank >= c->n || (len && !counts)) return fail(NIMBLE_E_INVALID, "nimble_counts_allreduce_host: bad argument");
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  nimble_comm::Shard &sh = c->shard[rank];
+  int rc = sh.vec.ensure(std::max<uint64_t>(len * 8, 16), nullptr);
+  if (rc) return rc;
+  hipStream_t s = sh.ctx ? sh.ctx->stream : nullptr;
+  if (len) HIPCHK(hipMemcpyAsync(sh.vec.p, counts, len * 8, hipMemcpyHostToDevice, s));
+  rc = nimble_counts_allreduce(c, rank, sh.vec.as<int64_t>(), len, s);
+  if (rc) return rc;
+  if (len) HIPCHK(hipMemcpyAsync(counts, sh.vec.p, len * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NIMBLE_OK;
+}
+
+int nimble_records_alltoall(nimble_comm *c, int rank, const uint64_t *send, const uint64_t *send_counts,
+                            uint32_t rec_words, uint64_t *recv, uint64_t recv_cap, uint64_t *n_recv, void *stream) {
+  if (!c || rank < 0 || rank >= c->n || !send_counts || !n_recv || rec_words == 0)
+    return fail(NIMBLE_E_INVALID, "nimble_records_alltoall: bad argument");
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  hipStream_t s = (hipStream_t)stream;
+  const int W = c->n;
+  int rc = NIMBLE_OK;
+  if (!c->rccl && hipStreamSynchronize(s) != hipSuccess) rc = NIMBLE_E_HIP;  // peers copy straight out of `send`
+  for (int d = 0; d < W; ++d) c->counts[(size_t)rank * W + d] = send_counts[d];
+  c->send_ptr[rank] = send;
+  rc = c->agree(rank, rc);
+  if (rc != NIMBLE_OK) return fail(rc, "nimble_records_alltoall: a rank failed");
+  uint64_t total = 0;
+  for (int src = 0; src < W; ++src) total += c->counts[(size_t)src * W + rank];
+  *n_recv = total;
+  rc = total > recv_cap ? NIMBLE_E_OVERFLOW : NIMBLE_OK;
+  rc = c->agree(rank, rc);  // nobody starts moving records unless everybody has room
+  if (rc != NIMBLE_OK) return fail(rc, "nimble_records_alltoall: a receive buffer is too small");
+  if (c->rccl) {
+    uint64_t so = 0, ro = 0;
+    NCCLCHK(ncclGroupStart());
+    for (int peer = 0; peer < W; ++peer) {
+      const uint64_t ns = send_counts[peer], nr = c->counts[(size_t)peer * W + rank];
+      if (ns) NCCLCHK(ncclSend(send + so * rec_words, ns * rec_words, ncclUint64, peer, c->comms[rank], s));
+      if (nr) NCCLCHK(ncclRecv(recv + ro * rec_words, nr * rec_words, ncclUint64, peer, c->comms[rank], s));
+      so += ns;
+      ro += nr;
+    }
+    NCCLCHK(ncclGroupEnd());
+    c->barrier();  // the count table is free for the next call
+    return NIMBLE_OK;
+  }
+  uint64_t ro = 0;
+  hipError_t e = hipSuccess;
+  for (int src = 0; src < W && e == hipSuccess; ++src) {
+    uint64_t so = 0;
+    for (int d = 0; d < rank; ++d) so += c->counts[(size_t)src * W + d];
+    const uint64_t nr = c->counts[(size_t)src * W + rank];
+    if (nr) e = hipMemcpyAsync(recv + ro * rec_words, c->send_ptr[src] + so * rec_words, nr * rec_words * 8,
+                               hipMemcpyDeviceToDevice, s);
+    ro += nr;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  rc = c->agree(rank, e == hipSuccess ? NIMBLE_OK : NIMBLE_E_HIP);  // send buffers may be refilled after this
+  if (rc != NIMBLE_OK) return fail(rc, "nimble_records_alltoall: device copy failed");
+  return NIMBLE_OK;
+}
+
+// ---- one score::call whose reads are spread over the ranks: every rank appends its share batch by batch (pack where the
+//      reads are, route by key hash, all-to-all, keep what it owns) and finally runs the call over the records it owns.
+int nimble_sharded_begin(nimble_comm *c, int rank, nimble_ctx *ctx, const nimble_align_params *p, int paired,
+                         uint32_t max_len) {
+  if (!c || rank < 0 || rank >= c->n || !ctx || !p) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: bad argument");
+  if (ctx->ix->device != c->devices[rank]) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: the context's index is on another device");
+  if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: bad max_len");
+  nimble_comm::Shard &sh = c->shard[rank];
+  sh.ctx = ctx;
+  sh.prm = *p;
+  sh.paired = paired ? 1 : 0;
+  sh.max_len = max_len;
+  sh.rec_words = nimble_key_words(max_len, paired) + 2;
+  sh.n_acc = 0;
+  sh.open = true;
+  return NIMBLE_OK;
+}
+
+int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                          const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem) {
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_append: bad argument");
+  nimble_comm::Shard &sh = c->shard[rank];
+  nimble_ctx *ctx = sh.ctx;
+  const int W = c->n;
+  // (a failure of one rank must not leave the others waiting at a barrier: local errors are carried to the collectives)
+  int rc = sh.open ? NIMBLE_OK : fail(NIMBLE_E_INVALID, "nimble_sharded_append: no sharded call is open on this rank");
+  uint32_t max_len = sh.max_len;
+  if (rc == NIMBLE_OK && (r2 != nullptr) != (sh.paired != 0)) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: mates given for a single-end call or missing for a paired one");
+  if (rc == NIMBLE_OK && !r1_off && fixed_len > max_len) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: a read longer than max_len");
+  if (rc == NIMBLE_OK) rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  std::vector<uint64_t> counts(W, 0);
+  const uint32_t rw = sh.rec_words;
+  if (rc == NIMBLE_OK && hipSetDevice(c->devices[rank]) != hipSuccess) rc = fail(NIMBLE_E_HIP, "hipSetDevice");
+  if (rc == NIMBLE_OK && n) {
+    if (ctx->called && !ctx->finished) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: the context holds a call in flight");
+    if (rc == NIMBLE_OK) rc = stage_inputs(ctx, r1, r1_off, r2, r2_off, n, fixed_len, sh.max_len, mem);
+    if (rc == NIMBLE_OK) rc = setup_call(ctx, &sh.prm, n, r2 != nullptr, sh.max_len, nullptr);
+    if (rc == NIMBLE_OK) {
+      launch_pack(ctx->stream, ctx->in_r[0], ctx->in_off[0], ctx->in_r[1], ctx->in_off[1], ctx->in_fixed_len, ctx->in_max_len,
+                  ctx->prm.min_read_length, ctx->b_plog.as<double>(), ctx->plog_max_len, ctx->cb);
+      const uint64_t cells = (uint64_t)route_grid() * W;
+      rc = ctx->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &ctx->bytes);
+      if (rc == NIMBLE_OK) rc = sh.send.ensure(std::max<uint64_t>(n * rw * 8, 16), nullptr);
+    }
+    if (rc == NIMBLE_OK) {
+      const uint64_t cells = (uint64_t)route_grid() * W;
+      uint64_t *block_first = ctx->b_route.as<uint64_t>();
+      uint64_t *totals = block_first + cells;
+      uint32_t *block_counts = reinterpret_cast<uint32_t *>(totals + 256);
+      launch_route(ctx->stream, ctx->cb, (uint32_t)W, block_counts, block_first, totals, sh.send.as<uint64_t>());
+      uint64_t latch = 0;
+      if (hipMemcpyAsync(counts.data(), totals, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(&latch, (uint64_t *)ctx->b_state.p + 14, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = fail(NIMBLE_E_HIP, "nimble_sharded_append: routing failed");
+      else if (latch != 0) {
+        (void)hipMemsetAsync((uint64_t *)ctx->b_state.p + 14, 0, 8, ctx->stream);
+        rc = fail(NIMBLE_E_INVALID, "offsets not monotone or a read longer than max_len (found on the device)");
+      }
+    }
+  }
+  const std::string my_error = rc == NIMBLE_OK ? std::string() : g_err;
+  if (rc != NIMBLE_OK) std::fill(counts.begin(), counts.end(), 0);
+  // room for what the others send: the incoming total is known only after everybody has published its counts, so the
+  // exchange runs in two steps -- counts first (host memory of this process), then the records
+  for (int d = 0; d < W; ++d) c->counts[(size_t)rank * W + d] = counts[d];
+  int all = c->agree(rank, rc);
+  uint64_t incoming = 0;
+  for (int src = 0; src < W; ++src) incoming += c->counts[(size_t)src * W + rank];
+  c->barrier();
+  if (all != NIMBLE_OK) return rc != NIMBLE_OK ? fail(rc, my_error) : fail(all, "nimble_sharded_append: another rank failed");
+  if (sh.n_acc + incoming > sh.acc_cap) {  // grow the rank's store of owned records (contents kept)
+    const uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(2 * sh.acc_cap, sh.n_acc + incoming), 1u << 16);
+    DevBuf nb;
+    int r2c = nb.ensure(cap * rw * 8, nullptr);
+    if (r2c == NIMBLE_OK && sh.n_acc &&
+        (hipMemcpyAsync(nb.p, sh.acc.p, sh.n_acc * rw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+         hipStreamSynchronize(ctx->stream) != hipSuccess))
+      r2c = NIMBLE_E_HIP;
+    if (r2c == NIMBLE_OK) {
+      sh.acc.release();
+      sh.acc = nb;
+      sh.acc_cap = cap;
+    } else {
+      nb.release();
+      rc = fail(r2c, "nimble_sharded_append: out of device memory for the owned records");
+    }
+  }
+  all = c->agree(rank, rc);
+  if (all != NIMBLE_OK) return rc != NIMBLE_OK ? rc : fail(all, "nimble_sharded_append: another rank failed");
+  uint64_t got = 0;
+  rc = nimble_records_alltoall(c, rank, sh.send.as<uint64_t>(), counts.data(), rw, sh.acc.as<uint64_t>() + sh.n_acc * rw,
+                               sh.acc_cap - sh.n_acc, &got, ctx->stream);
+  if (rc) return rc;
+  // the send buffer is refilled by the next append: the exchange must have left it (RCCL runs on the stream)
+  if (c->rccl) HIPCHK(hipStreamSynchronize(ctx->stream));
+  sh.n_acc += got;
+  return NIMBLE_OK;
+}
+
+int nimble_sharded_end(nimble_comm *c, int rank, uint64_t *n_owned) {
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_end: bad argument");
+  nimble_comm::Shard &sh = c->shard[rank];
+  if (!sh.open) return fail(NIMBLE_E_INVALID, "nimble_sharded_end: no sharded call is open on this rank");
+  sh.open = false;
+  if (n_owned) *n_owned = sh.n_acc;
+  return nimble_call_records(sh.ctx, &sh.prm, sh.acc.as<uint64_t>(), sh.n_acc, sh.max_len, sh.paired);
 }
 
 }  // extern "C"

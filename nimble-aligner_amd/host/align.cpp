@@ -444,6 +444,8 @@ static nimble_align_params make_params(const AlignFilterConfig &config) {
   return p;
 }
 
+void device_params(const AlignFilterConfig &config, nimble_align_params *out) { *out = make_params(config); }
+
 static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                                const AlignFilterConfig &config, bool want_per_read,
                                std::chrono::steady_clock::time_point t0, int slot = 0);

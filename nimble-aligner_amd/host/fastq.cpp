@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
+#include <map>
+#include <algorithm>
 #include <mutex>
 #include <thread>
 
@@ -633,6 +636,138 @@ void process(const std::vector<std::string> &input_files,
   if (getenv("NIMBLE_HOST_TIMING"))
     fprintf(stderr, "[nimble host] fastq pipeline (parse + device + tsv) %.3f s, ingest batch %zu records\n",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), batch);
+}
+
+namespace {
+
+// run f(rank) on one thread per rank and wait for all of them; the first exception is re-thrown here
+template <class F>
+void on_every_rank(int world, F f) {
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)world);
+  for (int r = 0; r < world; ++r)
+    th.emplace_back([&, r] {
+      try {
+        f(r);
+      } catch (...) {
+        err[(size_t)r] = std::current_exception();
+      }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+void check_dev(int rc, const char *what) {
+  if (rc != 0) throw Panic(std::string(what) + ": " + nimble_last_error());
+}
+
+}  // namespace
+
+void process_sharded(const std::vector<std::string> &input_files,
+                     std::vector<std::vector<std::unique_ptr<align::PseudoAligner>>> &reference_indices,
+                     const std::vector<reference_library::Reference> &references,
+                     const std::vector<align::AlignFilterConfig> &aligner_configs,
+                     const std::vector<std::string> &output_paths, const std::vector<int> &devices) {
+  const int W = (int)devices.size();
+  if (W < 1) throw Panic("process_sharded: no device given");
+  const auto t0 = std::chrono::steady_clock::now();
+  nimble_comm *comm = nullptr;
+  check_dev(nimble_comm_create(devices.data(), W, &comm), "nimble_comm_create");
+  struct CommGuard {
+    nimble_comm *c;
+    ~CommGuard() { nimble_comm_free(c); }
+  } guard{comm};
+  size_t batch = 1u << 19;
+  if (const char *e = getenv("NIMBLE_FASTQ_BATCH")) batch = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1024);
+  const bool paired = input_files.size() > 1;
+  const std::string lengths = "Error -- read and reverse read files do not have matching lengths: ";
+  // one library after the other, each over the whole input (src/process/fastq.rs:15)
+  for (size_t li = 0; li < reference_indices.size(); ++li) {
+    auto &ranks = reference_indices[li];
+    if ((int)ranks.size() != W) throw Panic("process_sharded: one index per rank is needed");
+    nimble_align_params prm;
+    align::device_params(aligner_configs.at(li), &prm);
+    uint32_t max_len = 0;
+    for (;;) {  // (again from the start if a later batch holds a read longer than the call was opened for)
+      bool too_long = false;
+      Cursor c1(input_files.at(0), false, batch);
+      std::unique_ptr<Cursor> c2;
+      if (paired) c2.reset(new Cursor(input_files[1], true, batch));
+      bool begun = false;
+      for (;;) {
+        c1.fill();
+        if (paired) c2->fill();
+        const uint64_t n = paired ? std::min(c1.avail(), c2->avail()) : c1.avail();
+        const uint32_t ml = std::max<uint32_t>(c1.b->data.max_len, paired ? c2->b->data.max_len : 0u);
+        if (!begun) {
+          max_len = std::max<uint32_t>(max_len, std::max<uint32_t>(32, (ml + 31u) / 32u * 32u));
+          on_every_rank(W, [&](int r) {
+            check_dev(nimble_sharded_begin(comm, r, ranks[(size_t)r]->ctx(), &prm, paired ? 1 : 0, max_len),
+                      "nimble_sharded_begin");
+          });
+          begun = true;
+        }
+        if (ml > max_len) {
+          max_len = (ml + 31u) / 32u * 32u;
+          too_long = true;
+          break;
+        }
+        if (n) {
+          const uint64_t *o1 = c1.b->data.offsets.data() + c1.used;
+          const uint64_t *o2 = paired ? c2->b->data.offsets.data() + c2->used : nullptr;
+          const uint8_t *b1 = c1.b->data.bases.data();
+          const uint8_t *b2 = paired ? c2->b->data.bases.data() : nullptr;
+          // one round: rank r packs reads [n r / W, n (r + 1) / W) of the slice, the packed reads go to their owners
+          on_every_rank(W, [&](int r) {
+            const uint64_t lo = n * (uint64_t)r / (uint64_t)W, hi = n * (uint64_t)(r + 1) / (uint64_t)W;
+            check_dev(nimble_sharded_append(comm, r, b1, o1 + lo, b2, paired ? o2 + lo : nullptr, hi - lo, 0,
+                                            NIMBLE_MEM_HOST),
+                      "nimble_sharded_append");
+          });
+          c1.used += n;
+          if (paired) c2->used += n;
+          continue;
+        }
+        if (c1.at_end()) {
+          if (!c1.b->error.empty()) throw Panic(c1.b->error);
+          break;
+        }
+        throw Panic(c2->b->error.empty() ? lengths : c2->b->error);
+      }
+      if (!too_long) break;
+      on_every_rank(W, [&](int r) { (void)nimble_sharded_end(comm, r, nullptr); });  // close, then start over
+    }
+    // every rank: the call over the reads it owns, its rows; the callsets are agreed by content (this is one
+    // process: a shared dictionary), the counts summed by an all-reduce of one int64 vector
+    std::mutex mu;
+    std::map<std::vector<std::string>, size_t> dict;
+    std::vector<std::vector<align::ScoreRow>> rows((size_t)W);
+    on_every_rank(W, [&](int r) {
+      uint64_t owned = 0;
+      check_dev(nimble_sharded_end(comm, r, &owned), "nimble_sharded_end");
+      align::CallOutput out = align::end_calls(owned, *ranks[(size_t)r], references.at(li), aligner_configs.at(li), 0);
+      out.materialize();
+      rows[(size_t)r] = std::move(out.rows);
+      std::lock_guard<std::mutex> lk(mu);
+      for (const auto &row : rows[(size_t)r]) dict.emplace(row.first, 0);
+    });
+    size_t k = 0;
+    for (auto &kv : dict) kv.second = k++;  // std::map order == Vec<String> order == the order of the TSV
+    std::vector<std::vector<int64_t>> vec((size_t)W, std::vector<int64_t>(dict.size(), 0));
+    on_every_rank(W, [&](int r) {
+      for (const auto &row : rows[(size_t)r]) vec[(size_t)r][dict.at(row.first)] += row.second;
+      check_dev(nimble_counts_allreduce_host(comm, r, vec[(size_t)r].data(), vec[(size_t)r].size()),
+                "nimble_counts_allreduce_host");
+    });
+    std::vector<align::ScoreRow> result;
+    for (const auto &kv : dict) result.emplace_back(kv.first, (int32_t)vec[0][kv.second]);
+    utils::write_to_tsv(result, output_paths.at(li));
+  }
+  if (getenv("NIMBLE_HOST_TIMING"))
+    fprintf(stderr, "[nimble host] fastq pipeline (parse + device + tsv) %.3f s, %d ranks%s\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), W,
+            nimble_comm_uses_rccl(comm) ? " over RCCL" : " on one device");
 }
 
 }  // namespace fastq

@@ -428,6 +428,20 @@ int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, ni
   });
 }
 
+int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble_library *lib, const int *devices,
+                                 int n_devices, const char *output) {
+  return guarded([&] {
+    if (!lib || !devices || n_devices < 1) throw Panic("nimble_fastq_process_sharded: bad argument");
+    std::vector<std::string> in;
+    for (int i = 0; i < n_inputs; ++i) in.push_back(inputs[i]);
+    const std::vector<int> dev(devices, devices + n_devices);
+    auto data = utils::get_reference_sequence_data(lib->ref);
+    std::vector<std::vector<std::unique_ptr<align::PseudoAligner>>> idx(1);
+    for (int d : dev) idx[0].push_back(align::PseudoAligner::build_index(data.first, data.second, d));
+    process::fastq::process_sharded(in, idx, {lib->ref}, {lib->cfg}, {std::string(output)}, dev);
+  });
+}
+
 int nimble_write_to_tsv(const nimble_rows *r, const char *path) {
   return guarded([&] {
     align::CallOutput copy;

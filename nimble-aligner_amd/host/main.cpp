@@ -28,7 +28,8 @@ namespace {
           "    -r, --reference <reference>...     Reference libraries in nimble .json format\n"
           "    -f, --strand_filter <STRAND_FILTER>  unstranded (default), fiveprime, threeprime, none\n"
           "    -t, --trim <TRIM>                  <TARGET_LENGTH>:<STRICTNESS>, comma-separated, one per library\n"
-          "    -d, --device <ORDINAL>             HIP device to run on [default: 0]\n");
+          "    -d, --device <ORDINAL>[,<ORDINAL>...]  HIP device(s) to run on [default: 0]; several = one rank per device,\n"
+          "                                       reads exchanged and counts summed over RCCL (FASTQ input)\n");
   exit(msg ? 1 : 0);
 }
 
@@ -45,7 +46,7 @@ int main(int argc, char **argv) {
   std::vector<std::string> refs, outs, ins;
   std::string cores = "1", strand = "unstranded", trim;
   bool have_trim = false, have_cores = false;
-  int device = 0;
+  std::vector<int> devices{0};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto multi = [&](std::vector<std::string> &dst) {
@@ -62,7 +63,17 @@ int main(int argc, char **argv) {
     else if (a == "-f" || a == "--strand_filter") single(strand);
     else if (a == "-t" || a == "--trim") { single(trim); have_trim = true; }
     else if (a == "-p" || a == "--force_bam_paired") { /* BAM only */ }
-    else if (a == "-d" || a == "--device") { std::string d; single(d); device = atoi(d.c_str()); }
+    else if (a == "-d" || a == "--device") {
+      std::string d;
+      single(d);
+      devices.clear();
+      for (size_t p = 0; p <= d.size();) {
+        size_t q = d.find(',', p);
+        devices.push_back(atoi(d.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+        if (q == std::string::npos) break;
+        p = q + 1;
+      }
+    }
     else if (a == "-h" || a == "--help") usage(nullptr);
     else if (a == "-V" || a == "--version") { puts("nimble 0.8.0-mi355x"); return 0; }
     else usage(("unexpected argument " + a).c_str());
@@ -114,6 +125,8 @@ int main(int argc, char **argv) {
     }
 
     std::vector<std::unique_ptr<align::PseudoAligner>> indices;
+    std::vector<std::vector<std::unique_ptr<align::PseudoAligner>>> rank_indices;  // [library][rank], several devices
+    const bool sharded = devices.size() > 1;
     std::vector<reference_library::Reference> references;
     std::vector<align::AlignFilterConfig> configs;
     for (size_t i = 0; i < refs.size(); ++i) {
@@ -126,14 +139,20 @@ int main(int argc, char **argv) {
                pr.first.trim_target_length, pr.first.trim_strictness);
       }
       auto data = utils::get_reference_sequence_data(pr.second);
-      indices.push_back(align::PseudoAligner::build_index(data.first, data.second, device));
+      if (!sharded) {
+        indices.push_back(align::PseudoAligner::build_index(data.first, data.second, devices[0]));
+      } else {  // the library's index on every rank's device
+        rank_indices.emplace_back();
+        for (int dv : devices) rank_indices.back().push_back(align::PseudoAligner::build_index(data.first, data.second, dv));
+      }
       references.push_back(std::move(pr.second));
       configs.push_back(pr.first);
     }
     puts("Loading read sequences and aligning");
     if (is_fastq_gz || ext == "fastq") {
       puts("Processing as FASTQ file");
-      process::fastq::process(ins, indices, references, configs, outs);
+      if (sharded) process::fastq::process_sharded(ins, rank_indices, references, configs, outs, devices);
+      else process::fastq::process(ins, indices, references, configs, outs);
     } else if (ext == "bam") {
       throw Panic("BAM input is not supported by the MI355X build (FASTQ pipeline only)");
     } else {

@@ -24,6 +24,7 @@
 struct nimble_index;
 struct nimble_ctx;
 struct nimble_packed;
+struct nimble_align_params;
 
 namespace nimble {
 
@@ -269,6 +270,9 @@ class Coercer {
   std::shared_ptr<Impl> impl_;
 };
 
+// the part of the config the device path reads (include/nimble_hip.h nimble_align_params)
+void device_params(const AlignFilterConfig &config, nimble_align_params *out);
+
 // BAM-only quality trimming (src/align.rs:866-942), kept for parity of the unit-level surface
 size_t maxinfo(const std::string &quality, size_t target_length, double strictness);
 
@@ -337,6 +341,17 @@ void process(const std::vector<std::string> &input_files,
              const std::vector<reference_library::Reference> &references,
              const std::vector<align::AlignFilterConfig> &aligner_configs,
              const std::vector<std::string> &output_paths);
+// The same pipeline over several GPUs of one node: one rank (host thread) per device, no torch (include/nimble_hip.h
+// nimble_comm_* / nimble_sharded_*).  reference_indices[library][rank]: the library's index on each rank's device.  Every
+// batch of the input is split over the ranks; each packs its share, the packed reads travel to the rank that owns their
+// key (RCCL all-to-all), each rank runs the call over what it owns, the callsets are agreed by content and the count
+// vectors summed with an RCCL all-reduce; rank 0 writes the TSV.  `devices` may name one device several times (ranks
+// sharing a GPU: rehearsal and tests on a one-GPU box).
+void process_sharded(const std::vector<std::string> &input_files,
+                     std::vector<std::vector<std::unique_ptr<align::PseudoAligner>>> &reference_indices,
+                     const std::vector<reference_library::Reference> &references,
+                     const std::vector<align::AlignFilterConfig> &aligner_configs,
+                     const std::vector<std::string> &output_paths, const std::vector<int> &devices);
 }  // namespace fastq
 }  // namespace process
 

@@ -1,0 +1,159 @@
+"""The multi-GPU path of the C ABI (include/nimble_hip.h nimble_comm_* / nimble_sharded_*) and the C++ pipeline over it
+(process::fastq::process_sharded, `lib/nimble -d 0,1,...`): one process, one rank = one host thread per device, no torch.
+On a one-GPU box the ranks share the device (devices = [0, 0, ...]: records and counts move by device copies) and a
+communicator of ONE rank runs the real RCCL calls; every configuration must write the single-GPU table, which equals the
+CPU oracle's."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+nim = importlib.import_module("nimble-aligner_amd")
+synth = importlib.import_module("nimble-aligner_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def lib_and_reads(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sharded")
+    names, seqs = synth.make_library(48)
+    path = str(d / "lib.json")
+    synth.write_library(path, names, seqs)
+    r1, r2 = synth.make_reads(seqs, 60_000, paired=True, seed=77)
+    # copies of earlier reads far apart in the file: they land in different batches and on different ranks, and must
+    # still count once (the dedup scope is the whole call)
+    r1[50_000:50_400], r2[50_000:50_400] = r1[100:500], r2[100:500]
+    f1, f2 = str(d / "r1.fastq"), str(d / "r2.fastq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    return path, names, seqs, r1, r2, f1, f2, d
+
+
+def oracle_tsv(path, strand, r1, r2=None):
+    import json
+    obj = json.load(open(path))
+    names, seqs = obj[1]["columns"][1], obj[1]["columns"][3]
+    cols = [obj[1]["columns"][0], names, obj[1]["columns"][2], seqs]
+    ref = ora.Reference.from_columns(obj[1]["headers"], cols, obj[0].get("group_on", ""))
+    cfg = ora.config_from_json(obj[0], len(names), strand)
+    o = synth.fixed_offsets(r1.shape[0], r1.shape[1])
+    res = ora.call(ora.Index.from_reference(ref), ref, cfg, r1.reshape(-1), o, None if r2 is None else r2.reshape(-1),
+                   None if r2 is None else o)
+    return "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in res.rows)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("paired", [False, True])
+def test_sharded_fastq_pipeline_equals_one_call(lib_and_reads, devices, paired, monkeypatch):
+    path, names, seqs, r1, r2, f1, f2, d = lib_and_reads
+    monkeypatch.setenv("NIMBLE_FASTQ_BATCH", "8192")        # several rounds, ragged last one
+    want = oracle_tsv(path, "unstranded", r1, r2 if paired else None)
+    lib = nim.Library(path, "unstranded")
+    out = str(d / ("out_%d_%d.tsv" % (len(devices), int(paired))))
+    if os.path.exists(out):
+        os.remove(out)
+    nim.fastq_process_sharded([f1, f2] if paired else [f1], lib, devices, out)
+    assert open(out).read() == want
+
+
+def test_cli_device_list(lib_and_reads):
+    path, names, seqs, r1, r2, f1, f2, d = lib_and_reads
+    exe = os.path.join(ROOT, "nimble-aligner_amd", "lib", "nimble")
+    out = str(d / "cli.tsv")
+    cp = subprocess.run([exe, "-r", path, "-o", out, "-i", f1, "-f", "unstranded", "-d", "0,0"], capture_output=True,
+                        text=True, timeout=300, env=dict(os.environ, NIMBLE_FASTQ_BATCH="16384", NIMBLE_HOST_TIMING="1"))
+    assert cp.returncode == 0, cp.stderr
+    assert "2 ranks" in cp.stderr
+    assert open(out).read() == oracle_tsv(path, "unstranded", r1)
+
+
+def test_collectives_of_the_c_abi_with_three_ranks_on_one_device():
+    """nimble_counts_allreduce (device and host form) and nimble_records_alltoall called as a Rust host would: one
+    thread per rank."""
+    torch = pytest.importorskip("torch")
+    L = nim.hip_lib()
+    W = 3
+    comm = C.c_void_p()
+    dev = (C.c_int * W)(0, 0, 0)
+    assert L.nimble_comm_create(dev, W, C.byref(comm)) == 0
+    assert L.nimble_comm_size(comm) == W and L.nimble_comm_uses_rccl(comm) == 0
+    rw = 7
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 50, size=(W, W)).astype(np.uint64)      # [src][dst]
+    send = [rng.integers(0, 1 << 60, size=(int(counts[s].sum()), rw)).astype(np.uint64) for s in range(W)]
+    vecs = [rng.integers(0, 1000, size=257).astype(np.int64) for _ in range(W)]
+    got, errs = {}, []
+
+    def rank(r):
+        try:
+            s = torch.cuda.Stream()
+            v = torch.from_numpy(vecs[r].copy()).to("cuda:0")
+            torch.cuda.synchronize()
+            assert L.nimble_counts_allreduce(comm, r, v.data_ptr(), v.numel(), s.cuda_stream) == 0
+            hv = vecs[r].copy()
+            assert L.nimble_counts_allreduce_host(comm, r, hv.ctypes.data, hv.size) == 0
+            sd = torch.from_numpy(send[r].view(np.int64).copy()).to("cuda:0")
+            cap = int(counts[:, r].sum())
+            rv = torch.zeros((max(cap, 1), rw), dtype=torch.int64, device="cuda:0")
+            torch.cuda.synchronize()
+            n = C.c_uint64(0)
+            cr = counts[r].copy()
+            assert L.nimble_records_alltoall(comm, r, sd.data_ptr(), cr.ctypes.data, rw, rv.data_ptr(), cap, C.byref(n),
+                                             s.cuda_stream) == 0
+            s.synchronize()
+            got[r] = (v.cpu().numpy(), hv, rv[:n.value].cpu().numpy().view(np.uint64), n.value)
+        except Exception as e:               # noqa: BLE001
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    total = sum(vecs)
+    for r in range(W):
+        v, hv, rv, n = got[r]
+        np.testing.assert_array_equal(v, total)
+        np.testing.assert_array_equal(hv, total)
+        parts = []
+        for s in range(W):
+            lo = int(counts[s, :r].sum())
+            parts.append(send[s][lo:lo + int(counts[s, r])])
+        np.testing.assert_array_equal(rv, np.concatenate(parts))
+        assert n == int(counts[:, r].sum())
+    L.nimble_comm_free(comm)
+
+
+def test_rccl_communicator_of_one_rank():
+    """the real RCCL calls (all-reduce, grouped send/recv to oneself) on the one device this box has"""
+    torch = pytest.importorskip("torch")
+    L = nim.hip_lib()
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert L.nimble_comm_create(dev, 1, C.byref(comm)) == 0
+    assert L.nimble_comm_uses_rccl(comm) == 1
+    s = torch.cuda.Stream()
+    v = torch.arange(1000, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    assert L.nimble_counts_allreduce(comm, 0, v.data_ptr(), v.numel(), s.cuda_stream) == 0
+    s.synchronize()
+    assert torch.equal(v.cpu(), torch.arange(1000, dtype=torch.int64))
+    sd = torch.arange(35, dtype=torch.int64, device="cuda:0")
+    rv = torch.zeros(35, dtype=torch.int64, device="cuda:0")
+    cnt = np.array([5], dtype=np.uint64)
+    n = C.c_uint64(0)
+    torch.cuda.synchronize()
+    assert L.nimble_records_alltoall(comm, 0, sd.data_ptr(), cnt.ctypes.data, 7, rv.data_ptr(), 5, C.byref(n),
+                                     s.cuda_stream) == 0
+    s.synchronize()
+    assert n.value == 5 and torch.equal(rv, sd)
+    L.nimble_comm_free(comm)
