@@ -167,24 +167,49 @@ def exchange_routed(rec, counts, group=None, alloc=None, staging=None, with_coun
 
 
 class TableReducer:
-    """Per-callset counts summed over ranks, call after call.  The union of the callsets is agreed on once (one
-    all_gather_object) and kept; as long as no rank's key list changes, a call moves only a dense int64 vector
-    (one all_reduce; its last element flags a change, which triggers a new agreement)."""
+    """Per-callset counts summed over ranks, call after call.  Every rank holds the same table of callsets (the
+    universe); a call moves one dense int64 vector (one all_reduce) whose last element flags a rank that met a callset
+    the table does not hold.  Only then the table grows, and only by what is new: each rank contributes the callsets
+    ITS table lacks -- since the tables are identical, that is exactly what nobody has -- as one byte string (two small
+    all_gathers: lengths, then bytes); nothing that was agreed before travels again."""
 
     def __init__(self, device, group=None):
         self.device, self.group = device, group
         self.sig = None          # digest of this rank's key list at the last agreement
-        self.universe = []       # sorted union of the keys of all ranks
+        self.universe = []       # sorted union of the keys of all ranks (Vec<String> order)
+        self.pos = {}            # key -> position in the universe
         self.local2uni = None    # position of each local row in the universe
         self.staging = _Staging(device)
+        self.agreements = 0      # how often the table grew / how many key bytes this rank sent for it (diagnostics)
+        self.bytes_sent = 0
 
     def _agree(self, keys):
         world = dist.get_world_size(self.group)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, keys, group=self.group)
-        self.universe = sorted(set(k for ks in gathered for k in ks), key=lambda s: s.split("\t"))
-        pos = {k: i for i, k in enumerate(self.universe)}
-        self.local2uni = np.asarray([pos[k] for k in keys], dtype=np.int64)
+        fresh = [k for k in keys if k not in self.pos]
+        blob = "\n".join(fresh).encode("utf-8")     # callsets are '\t'-joined feature names: no newline inside
+        size = torch.tensor([len(blob)], dtype=torch.int64, device=self.device)
+        sizes = torch.empty(world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(sizes, size, group=self.group)
+        sizes = sizes.tolist()
+        width = max(sizes)
+        self.agreements += 1
+        self.bytes_sent += len(blob)
+        if width:
+            mine = torch.zeros(width, dtype=torch.uint8, device=self.device)
+            if blob:
+                mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            every = torch.empty(world * width, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            every = every.cpu().numpy().reshape(world, width)
+            added = set()
+            for r in range(world):
+                if sizes[r]:
+                    added.update(every[r, :sizes[r]].tobytes().decode("utf-8").split("\n"))
+            added.difference_update(self.pos)
+            if added:
+                self.universe = sorted(self.universe + list(added), key=lambda s: s.split("\t"))
+                self.pos = {k: i for i, k in enumerate(self.universe)}
+        self.local2uni = np.asarray([self.pos[k] for k in keys], dtype=np.int64)
 
     def reduce(self, keys_fn, counts, sig):
         """keys_fn() -> list of '\t'-joined callsets (only called when an agreement is needed); counts: int64

@@ -180,7 +180,7 @@ def _reducer_worker(rank, world, port, q):
     k2 = k + (["e"] if rank == 1 else [])
     out.append(run(k2, [1, 1] + ([4] if rank == 1 else [])))
     out.append(run(k2, [0, 2] + ([0] if rank == 1 else [])))
-    q.put((rank, out, agreed, calls["keys"]))
+    q.put((rank, out, agreed, calls["keys"], red.bytes_sent, red.agreements))
     dist.destroy_process_group()
 
 
@@ -195,9 +195,12 @@ def test_table_reducer_caches_the_key_agreement():
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    for rank, out, agreed, total in res:
+    for rank, out, agreed, total, sent, agreements in res:
         assert out[0] == [(["a", "b"], 1), (["c"], 12), (["d"], 10)]
         assert out[1] == [(["a", "b"], 5), (["c"], 12), (["d"], 8)]
         assert out[2] == [(["a", "b"], 1), (["c"], 2), (["d"], 1), (["e"], 4)]
         assert out[3] == [(["c"], 2), (["d"], 2)]
         assert agreed == 1 and total == 2      # keys were exchanged once per change, not once per call
+        # ... and only what the shared table lacks travels: all of a rank's keys the first time ("a\tb\nc" / "c\nd"), then
+        # the one new callset from the rank that met it, nothing from the other
+        assert agreements == 2 and sent == (5 if rank == 0 else 3 + 1)

@@ -136,3 +136,61 @@ def test_config4_five_thousand_feature_index():
     assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
     st = nim.Context(borrowed=nim.host_lib().nimble_library_ctx(lib.h))  # context exists
     assert st.h
+
+
+def test_config4_properties_at_80m_reads_on_one_gpu():
+    """BASELINE.json configs[4] at its stated size -- 80 M x 150 bp reads against the 5 k-feature library -- as ONE call on
+    one GPU (12 GB of bases, ~11 GB of workspace of the 288 GB): determinism, conservation, permutation invariance, the
+    8-way decomposition by read key that the 8-GPU run makes (each shard = the keys one rank would own; the shards'
+    tables must add up to the whole), and the CPU oracle on a 1 M-read subsample."""
+    torch = pytest.importorskip("torch")
+    names, seqs = synth.make_library(5000)
+    obj = synth.library_json(names, seqs)
+    lib = nim.Library(text=json.dumps(obj), strand_filter="unstranded").build_index()
+    n = 80_000_000
+    reads = synth.make_reads_torch(seqs, n, device="cuda:0")
+    torch.cuda.synchronize()
+    base = table(lib, reads, n)
+    assert len(base) > 8000
+    ctx = lib.device_context()
+    ctx.n = n
+    hist_total = sum(c for _, _, c in ctx.histogram())
+    assert hist_total == ctx.counters()["unique_keys"] == sum(c for _, c in base)   # group_on is empty: nothing is triaged
+    assert all(c > 0 for _, c in base) and [f for f, _ in base] == sorted(f for f, _ in base)
+    assert table(lib, reads, n) == base                                              # determinism
+    perm = torch.randperm(n, device="cuda:0")
+    shuffled = reads[perm].contiguous()
+    del perm
+    torch.cuda.synchronize()
+    assert table(lib, shuffled, n) == base                                           # permutation invariance
+    del shuffled
+    # the decomposition of the multi-GPU run: shard r = the reads whose KEY (converted bases: N reads as A) hashes to r
+    merged = {}
+    h = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+    w = torch.arange(1, 151, device="cuda:0")
+    for lo in range(0, n, 1 << 22):
+        part = reads[lo:lo + (1 << 22)]
+        conv = torch.where(part == ord("N"), torch.full_like(part, ord("A")), part)
+        h[lo:lo + (1 << 22)] = (conv.to(torch.int64) * w).sum(dim=1)
+    shard_reads = 0
+    for r in range(8):
+        part = reads[(h % 8) == r].contiguous()
+        torch.cuda.synchronize()
+        shard_reads += part.shape[0]
+        for f, c in table(lib, part, part.shape[0]):
+            merged[tuple(f)] = merged.get(tuple(f), 0) + c
+        del part
+    assert shard_reads == n
+    assert sorted([list(k), v] for k, v in merged.items()) == [[f, c] for f, c in base]
+    del h
+    # oracle parity on a subsample
+    m = 1_000_000
+    sub = reads[:m].contiguous()
+    torch.cuda.synchronize()
+    got = table(lib, sub, m)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(obj[0], len(names), "unstranded")
+    exp = ora.call(ora.Index.from_reference(ref), ref, cfg, sub.cpu().numpy().reshape(-1), synth.fixed_offsets(m, 150),
+                   n_threads=16)
+    assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
