@@ -143,6 +143,16 @@ int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, ni
  * library's index is built on every rank's device for the run. */
 int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble_library *lib, const int *devices,
                                  int n_devices, const char *output);
+/* process::bam::process (src/process/bam.rs:45-243): a single BAM file, one gzip-compressed TSV per library.  The reader is
+ * this build's own (BGZF + BAM records on zlib, no htslib); the UMI grouping follows src/parse/sorted_bam_reader.rs and
+ * src/parse/bam.rs. */
+int nimble_bam_process(const char *input, int n_libs, nimble_library *const *libs, const char *const *outputs, int cores,
+                       int force_bam_paired);
+/* The UMI groups of a BAM file as the reference's UMIReader yields them, as text (needs no GPU; see host_capi.cpp). */
+int nimble_host_bam_dump(const char *input, int force_bam_paired, const char *out_path);
+/* process/bam.rs:407-423 */
+int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap);
+int nimble_host_parse_str_as_bool(const char *v, int *out);
 int nimble_write_to_tsv(const nimble_rows *, const char *output_path);
 
 /* host-only pieces, exposed for CPU tests of the host logic */

@@ -470,7 +470,8 @@ HOST_SYMBOLS = [
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
     "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
-    "nimble_fastq_process_sharded",
+    "nimble_fastq_process_sharded", "nimble_bam_process", "nimble_host_bam_dump", "nimble_host_reverse_comp_if_needed",
+    "nimble_host_parse_str_as_bool",
 ]
 
 
@@ -557,6 +558,10 @@ def host_lib():
         L.nimble_rows_get.restype = cp
         L.nimble_fastq_process.argtypes = [i32, pp, i32, C.POINTER(vp), pp]
         L.nimble_fastq_process_sharded.argtypes = [i32, pp, vp, C.POINTER(i32), i32, cp]
+        L.nimble_bam_process.argtypes = [cp, i32, C.POINTER(vp), pp, i32, i32]
+        L.nimble_host_bam_dump.argtypes = [cp, i32, cp]
+        L.nimble_host_reverse_comp_if_needed.argtypes = [cp, i32, cp, u64]
+        L.nimble_host_parse_str_as_bool.argtypes = [cp, C.POINTER(i32)]
         L.nimble_write_to_tsv.argtypes = [vp, cp]
         L.nimble_host_coerce.argtypes = [vp, i32, vp, i32, i32, vp, i32, cp, i32]
         L.nimble_host_natural_lexical_cmp.argtypes = [cp, cp]
@@ -984,6 +989,44 @@ def fastq_process_sharded(input_files, library, devices, output_path):
     ins = _cstrs(input_files)
     dev = (C.c_int * len(devices))(*devices)
     _hcheck(L.nimble_fastq_process_sharded(len(input_files), ins, library.h, dev, len(devices), output_path.encode()))
+
+
+def bam_process(input_file, libraries, output_paths, cores=1, force_bam_paired=False):
+    """process::bam::process (src/process/bam.rs:45-243)."""
+    arr = (C.c_void_p * len(libraries))(*[l.h for l in libraries])
+    _hcheck(host_lib().nimble_bam_process(input_file.encode(), len(libraries), arr, _cstrs(output_paths), cores,
+                                          int(force_bam_paired)))
+
+
+def bam_umi_groups(input_file, force_bam_paired=False):
+    """[(umi, cell barcode, dropped, [(sequence, [38 fields])])]: what UMIReader hands to the aligner (no GPU)."""
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".txt") as t:
+        _hcheck(host_lib().nimble_host_bam_dump(input_file.encode(), int(force_bam_paired), t.name.encode()))
+        groups = []
+        for line in open(t.name, "rb").read().decode("latin-1").split("\n"):
+            if not line:
+                continue
+            f = line.split("\t")
+            if f[0] in ("G", "G*"):
+                groups.append((f[1], f[2], f[0] == "G*", []))
+            else:
+                fields = f[2:]
+                fields[1] = bytes.fromhex(fields[1]).decode("latin-1")
+                groups[-1][3].append((f[1], fields))
+    return groups
+
+
+def reverse_comp_if_needed(seq, reverse_comp):
+    out = C.create_string_buffer(len(seq) + 8)
+    _hcheck(host_lib().nimble_host_reverse_comp_if_needed(seq.encode(), int(reverse_comp), out, len(out)))
+    return out.value.decode()
+
+
+def parse_str_as_bool(v):
+    r = C.c_int(0)
+    _hcheck(host_lib().nimble_host_parse_str_as_bool(v.encode(), C.byref(r)))
+    return bool(r.value)
 
 
 def natural_lexical_cmp(a, b):

@@ -431,6 +431,11 @@ void CallOutput::materialize() {
   for (size_t i = 0; i < refs.size(); ++i) rows.emplace_back(refs.features(i), refs.counts[i]);
 }
 
+static size_t kept_score(FilterReason r, uint32_t cls, int32_t score) {
+  const bool passed = r == FilterReason::SuccessfulMatch || (r == FilterReason::NotMatchingPair && cls != NIMBLE_CLASS_NONE);
+  return passed ? (size_t)score : 0;
+}
+
 static nimble_align_params make_params(const AlignFilterConfig &config) {
   nimble_align_params p;
   memset(&p, 0, sizeof p);
@@ -605,19 +610,23 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
   if (want_per_read) {
     out.per_read.resize(n_reads);
     std::vector<int32_t> r[2], s[2];
+    std::vector<uint32_t> cl[2];
     for (int m = 0; m < 2; ++m) {
       r[m].resize(n_reads);
       s[m].resize(n_reads);
-      check_rc(nimble_read_records(ctx, m, r[m].data(), s[m].data(), nullptr, nullptr, nullptr, n_reads),
+      cl[m].resize(n_reads);
+      check_rc(nimble_read_records(ctx, m, r[m].data(), s[m].data(), nullptr, cl[m].data(), nullptr, n_reads),
                "nimble_read_records");
     }
     for (uint64_t i = 0; i < n_reads; ++i) {
       FilterRecord &fr = out.per_read[i];
       fr.r1 = (FilterReason)r[0][i];
       fr.r2 = (FilterReason)r[1][i];
-      // the score slot of filter_reasons holds the score only for kept alignments (align.rs:561-572)
-      fr.score1 = fr.r1 == FilterReason::SuccessfulMatch ? (size_t)s[0][i] : 0;
-      fr.score2 = fr.r2 == FilterReason::SuccessfulMatch ? (size_t)s[1][i] : 0;
+      // the score slot of filter_reasons holds the score only for alignments that passed pseudoalign (align.rs:561-572);
+      // a pair dropped by require_valid_pair keeps the scores of the mates that had (align.rs:586: a passing mate still
+      // carries its class here)
+      fr.score1 = kept_score(fr.r1, cl[0][i], s[0][i]);
+      fr.score2 = kept_score(fr.r2, cl[1][i], s[1][i]);
       fr.triage = FilterReason::None;
     }
   }
@@ -721,8 +730,8 @@ UmiOutput get_calls_umis(const ReadBatch &seqs, const ReadBatch *mates, const Um
       FilterRecord &fr = out.per_read[i];
       fr.r1 = (FilterReason)r[0][i];
       fr.r2 = (FilterReason)r[1][i];
-      fr.score1 = fr.r1 == FilterReason::SuccessfulMatch ? (size_t)sc[0][i] : 0;
-      fr.score2 = fr.r2 == FilterReason::SuccessfulMatch ? (size_t)sc[1][i] : 0;
+      fr.score1 = kept_score(fr.r1, cl[0][i], sc[0][i]);
+      fr.score2 = kept_score(fr.r2, cl[1][i], sc[1][i]);
       fr.triage = FilterReason::None;
       // post_triaged_keys (align.rs:228-239): reads that reached the coercion and were dropped there
       const uint32_t a = cl[0][i], b = cl[1][i];

@@ -428,6 +428,73 @@ int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, ni
   });
 }
 
+int nimble_bam_process(const char *input, int n_libs, nimble_library *const *libs, const char *const *outputs, int cores,
+                       int force_bam_paired) {
+  return guarded([&] {
+    std::vector<std::unique_ptr<align::PseudoAligner>> idx;
+    std::vector<reference_library::Reference> refs;
+    std::vector<align::AlignFilterConfig> cfgs;
+    std::vector<std::string> out;
+    for (int i = 0; i < n_libs; ++i) {
+      if (!libs[i]->index) throw Panic("nimble_bam_process: a library has no index");
+      idx.push_back(std::move(libs[i]->index));
+      refs.push_back(libs[i]->ref);
+      cfgs.push_back(libs[i]->cfg);
+      out.push_back(outputs[i]);
+    }
+    try {
+      process::bam::process({std::string(input)}, idx, refs, cfgs, out, (size_t)std::max(cores, 1), force_bam_paired != 0);
+    } catch (...) {
+      for (int i = 0; i < n_libs; ++i) libs[i]->index = std::move(idx[(size_t)i]);
+      throw;
+    }
+    for (int i = 0; i < n_libs; ++i) libs[i]->index = std::move(idx[(size_t)i]);
+  });
+}
+
+// The UMI groups of a BAM file as the reference's UMIReader hands them to the aligner, one text line per item (no GPU
+// needed): "G <umi> <cell barcode>" opens a group, "R <sequence> <38 fields>" is a record of it (tab-separated; the QUAL
+// field, raw Phred bytes, in hex).  The last group is marked "G* ..." : the reference reads it and never sends it.
+int nimble_host_bam_dump(const char *input, int force_bam_paired, const char *out_path) {
+  return guarded([&] {
+    FILE *f = fopen(out_path, "w");
+    if (!f) throw Panic("nimble_host_bam_dump: cannot write the output file");
+    parse::bam::UMIReader reader(input, false, force_bam_paired != 0);
+    bool has_aligned = false;
+    for (;;) {
+      const bool final_umi = reader.next();
+      const bool dropped = final_umi && has_aligned;
+      if (dropped && reader.current_umi_group.empty()) break;  // (a file of one group: nothing is left over)
+      fprintf(f, "%s\t%s\t%s\n", dropped ? "G*" : "G", reader.current_umi.c_str(), reader.current_cell_barcode.c_str());
+      for (size_t i = 0; i < reader.current_umi_group.size(); ++i) {
+        fprintf(f, "R\t%s", reader.current_umi_group[i].c_str());
+        const auto &md = reader.current_metadata_group[i];
+        for (size_t k = 0; k < md.size(); ++k) {
+          fputc('\t', f);
+          if (k == 1) for (unsigned char c : md[k]) fprintf(f, "%02x", c);
+          else fputs(md[k].c_str(), f);
+        }
+        fputc('\n', f);
+      }
+      if (dropped) break;
+      has_aligned = true;
+    }
+    fclose(f);
+  });
+}
+
+int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap) {
+  return guarded([&] {
+    const std::string r = process::bam::reverse_comp_if_needed(seq, reverse_comp != 0);
+    if (r.size() + 1 > cap) throw Panic("nimble_host_reverse_comp_if_needed: buffer too small");
+    memcpy(out, r.c_str(), r.size() + 1);
+  });
+}
+
+int nimble_host_parse_str_as_bool(const char *v, int *out) {
+  return guarded([&] { *out = process::bam::parse_str_as_bool(v) ? 1 : 0; });
+}
+
 int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble_library *lib, const int *devices,
                                  int n_devices, const char *output) {
   return guarded([&] {

@@ -45,7 +45,7 @@ std::string lower(std::string s) {
 int main(int argc, char **argv) {
   std::vector<std::string> refs, outs, ins;
   std::string cores = "1", strand = "unstranded", trim;
-  bool have_trim = false, have_cores = false;
+  bool have_trim = false, have_cores = false, force_bam_paired = false;
   std::vector<int> devices{0};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
     else if (a == "-c" || a == "--cores") { single(cores); have_cores = true; }
     else if (a == "-f" || a == "--strand_filter") single(strand);
     else if (a == "-t" || a == "--trim") { single(trim); have_trim = true; }
-    else if (a == "-p" || a == "--force_bam_paired") { /* BAM only */ }
+    else if (a == "-p" || a == "--force_bam_paired") force_bam_paired = true;
     else if (a == "-d" || a == "--device") {
       std::string d;
       single(d);
@@ -154,7 +154,10 @@ int main(int argc, char **argv) {
       if (sharded) process::fastq::process_sharded(ins, rank_indices, references, configs, outs, devices);
       else process::fastq::process(ins, indices, references, configs, outs);
     } else if (ext == "bam") {
-      throw Panic("BAM input is not supported by the MI355X build (FASTQ pipeline only)");
+      puts("Processing as BAM file");
+      if (sharded) throw Panic("BAM input runs on one device (-d takes one ordinal)");
+      process::bam::process(ins, indices, references, configs, outs, (size_t)strtoull(cores.c_str(), nullptr, 10),
+                            force_bam_paired);
     } else {
       throw Panic("Unsupported file format: " + ext);
     }

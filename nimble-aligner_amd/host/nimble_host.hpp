@@ -331,9 +331,74 @@ class BatchReader {
   std::unique_ptr<Impl> impl_;
 };
 }  // namespace fastq
+namespace bam {
+// What the reference reads of a BAM record (rust_htslib::bam::Record), decoded from BGZF + BAM with zlib alone.
+struct Record {
+  int32_t tid = -1, pos = -1, mtid = -1, mpos = -1, tlen = 0;
+  uint32_t flag = 0, mapq = 0;
+  std::string qname, seq /* ASCII, "=ACMGRSVTWYHKDBN" */, qual /* raw Phred bytes */;
+  std::vector<uint8_t> aux;
+  std::string skip_align;  // the SKIP_ALIGN tag SortedBamReader pushes ("TRUE" / "FALSE"; empty = not pushed)
+  bool aux_string(const char *tag, std::string &out) const;  // Aux::String (type Z) only
+};
+extern const char *const BAM_FIELDS_TO_REPORT[38];  // src/parse/bam.rs:9-49
+class Reader {
+ public:
+  explicit Reader(const std::string &path);
+  ~Reader();
+  bool next(Record &r);  // false at end of file; panics on a truncated record
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+// src/parse/sorted_bam_reader.rs:6-186: records of one UMI at a time, ordered by cell barcode, dummies for unpaired reads
+class SortedBamReader {
+ public:
+  SortedBamReader(const std::string &path, bool force_bam_paired);
+  bool next(Record &out);
+ private:
+  void fill_buffer();
+  void add_dummy_paired_reads();
+  void filter_paired_reads();
+  Reader reader_;
+  bool force_bam_paired_;
+  std::string current_umi_, next_umi_;
+  std::vector<Record> buffer_, next_records_;
+  size_t cursor_ = 0;
+};
+// src/parse/bam.rs:51-288: one (UMI, cell barcode) group at a time: sequences with the non-biological bases clipped, and
+// the 38 reported fields per record
+class UMIReader {
+ public:
+  UMIReader(const std::string &path, bool terminate_on_error, bool force_bam_paired);
+  bool next();  // true = the final UMI has been read (the reference's `final_umi`)
+  std::vector<std::string> current_umi_group;
+  std::vector<std::vector<std::string>> current_metadata_group;
+  std::string current_umi, current_cell_barcode;
+ private:
+  bool get_umi_from_bam();
+  SortedBamReader reader_;
+  [[maybe_unused]] bool terminate_on_error_;  // the reference panics on every record error it meets, whatever this says
+  size_t read_counter_ = 0;
+  std::vector<std::string> next_umi_group_;
+  std::vector<std::vector<std::string>> next_metadata_group_;
+  std::string next_umi_, next_cell_barcode_, current_iteration_key_, next_iteration_key_;
+};
+}  // namespace bam
 }  // namespace parse
 
 namespace process {
+namespace bam {
+// src/process/bam.rs:45-243: one gzip-compressed TSV per library, a row per callset of every UMI group plus a row per pair
+// that stands for none
+void process(const std::vector<std::string> &input_files,
+             std::vector<std::unique_ptr<align::PseudoAligner>> &reference_indices,
+             const std::vector<reference_library::Reference> &references,
+             const std::vector<align::AlignFilterConfig> &aligner_configs, const std::vector<std::string> &output_paths,
+             size_t num_cores, bool force_bam_paired);
+std::string reverse_comp_if_needed(const std::string &seq, bool reverse_comp);  // process/bam.rs:407-415
+bool parse_str_as_bool(const std::string &v);                                   // process/bam.rs:417-423
+}  // namespace bam
 namespace fastq {
 // src/process/fastq.rs:7-30
 void process(const std::vector<std::string> &input_files,

@@ -892,6 +892,7 @@ struct Result {
   std::vector<std::pair<std::string, int32_t>> rows;  // features joined by '\t', count -- sorted
   std::vector<int32_t> reason[2], score[2], mism[2];
   std::vector<uint64_t> class_hash[2];
+  std::vector<uint8_t> kept[2];  // the mate's alignment passed pseudoalign (before the pair filter)
   std::vector<uint8_t> counted;
   uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // BAM-mode call (one score::call per UMI): segment id of every row, aligned (trimmed) length per read
@@ -981,11 +982,13 @@ void score_sequences(const Index &ix, const ora_config &cfg, const uint8_t *r1, 
       rec->score[0][i] = (int32_t)a1.walk_score;
       rec->mism[0][i] = (int32_t)a1.walk_mm;
       rec->class_hash[0][i] = a1.walk_some ? fnv_class(a1.cls) : 0;
+      rec->kept[0][i] = a1.some ? 1 : 0;
       if (have_mate) {
         rec->reason[1][i] = a2.some ? ORA_SUCCESSFUL_MATCH : a2.reason;
         rec->score[1][i] = (int32_t)a2.walk_score;
         rec->mism[1][i] = (int32_t)a2.walk_mm;
         rec->class_hash[1][i] = a2.walk_some ? fnv_class(a2.cls) : 0;
+        rec->kept[1][i] = a2.some ? 1 : 0;
       } else {
         rec->reason[1][i] = ORA_SUCCESSFUL_MATCH;  // align.rs:596-599: None -> SuccessfulMatch
       }
@@ -1036,6 +1039,7 @@ Result *call(const Index &ix, const Ref &ref, const ora_config &cfg, const uint8
       res->score[m].assign(n, 0);
       res->mism[m].assign(n, 0);
       res->class_hash[m].assign(n, 0);
+      res->kept[m].assign(n, 0);
     }
     res->counted.assign(n, 0);
     rec = res;
@@ -1111,6 +1115,7 @@ Result *call_umi(const Index &ix, const Ref &ref, const ora_config &cfg, const u
       res->score[m].assign(n, 0);
       res->mism[m].assign(n, 0);
       res->class_hash[m].assign(n, 0);
+      res->kept[m].assign(n, 0);
       res->align_len[m].assign(n, 0);
     }
     res->counted.assign(n, 0);
@@ -1454,6 +1459,7 @@ const int32_t *ora_result_reason(const ora_result *r, int m) { return r->r->reas
 const int32_t *ora_result_score(const ora_result *r, int m) { return r->r->score[m].data(); }
 const int32_t *ora_result_mismatch(const ora_result *r, int m) { return r->r->mism[m].data(); }
 const uint64_t *ora_result_class_hash(const ora_result *r, int m) { return r->r->class_hash[m].data(); }
+const uint8_t *ora_result_kept(const ora_result *r, int m) { return r->r->kept[m].data(); }
 const uint8_t *ora_result_counted(const ora_result *r) { return r->r->counted.data(); }
 void ora_result_counters(const ora_result *r, uint64_t *c8) { memcpy(c8, r->r->counters, sizeof(uint64_t) * 8); }
 

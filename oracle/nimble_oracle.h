@@ -163,7 +163,8 @@ const char *ora_result_row(const ora_result *, uint64_t i, int32_t *count);
 const int32_t *ora_result_reason(const ora_result *, int mate);   /* FilterReason per read */
 const int32_t *ora_result_score(const ora_result *, int mate);    /* raw score (bases covered) */
 const int32_t *ora_result_mismatch(const ora_result *, int mate); /* mismatches seen by the walk */
-const uint64_t *ora_result_class_hash(const ora_result *, int mate); /* FNV-1a of the passing class, 0 if none */
+const uint64_t *ora_result_class_hash(const ora_result *, int mate); /* FNV-1a of the walk's class, 0 if there was no walk */
+const uint8_t *ora_result_kept(const ora_result *, int mate); /* 1 = the mate's alignment passed pseudoalign (before filter_pair) */
 const uint8_t *ora_result_counted(const ora_result *);  /* 1 for the read that represents its key in score_map */
 /* counters for the roofline formula of SURVEY 8(d):
  * [0]=reads [1]=unique keys in score_map [2]=sum P (seed probes) [3]=sum U (nodes visited)

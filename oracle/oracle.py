@@ -112,6 +112,7 @@ def lib():
             "ora_result_score": (C.POINTER(C.c_int32), [vp, i32]),
             "ora_result_mismatch": (C.POINTER(C.c_int32), [vp, i32]),
             "ora_result_class_hash": (C.POINTER(C.c_uint64), [vp, i32]),
+            "ora_result_kept": (C.POINTER(C.c_uint8), [vp, i32]),
             "ora_result_counted": (C.POINTER(C.c_uint8), [vp]),
             "ora_result_counters": (None, [vp, C.POINTER(u64)]),
         }
@@ -370,6 +371,7 @@ def call(index, ref, cfg, r1, r1_off, r2=None, r2_off=None, n_threads=1, keep_pe
                 score=[arr(lib().ora_result_score(h, m), np.int32) for m in (0, 1)],
                 mismatches=[arr(lib().ora_result_mismatch(h, m), np.int32) for m in (0, 1)],
                 class_hash=[arr(lib().ora_result_class_hash(h, m), np.uint64) for m in (0, 1)],
+                kept=[arr(lib().ora_result_kept(h, m), np.uint8) for m in (0, 1)],
                 counted=arr(lib().ora_result_counted(h), np.uint8),
             )
         c = (C.c_uint64 * 8)()
@@ -423,6 +425,7 @@ def call_umi(index, ref, cfg, r1, r1_off, r2=None, r2_off=None, q1=None, q2=None
                 score=[arr(L.ora_result_score(h, m), np.int32) for m in (0, 1)],
                 mismatches=[arr(L.ora_result_mismatch(h, m), np.int32) for m in (0, 1)],
                 class_hash=[arr(L.ora_result_class_hash(h, m), np.uint64) for m in (0, 1)],
+                kept=[arr(L.ora_result_kept(h, m), np.uint8) for m in (0, 1)],
                 align_len=[arr(L.ora_result_align_len(h, m), np.int32) for m in (0, 1)],
                 counted=arr(L.ora_result_counted(h), np.uint8),
             )

@@ -1,0 +1,91 @@
+"""The BAM pipeline end to end on the GPU: process::bam::process (this build's BGZF/BAM reader, the reference's UMI
+grouping, many UMI groups per device call, the gzip TSV of src/process/bam.rs:92-121) against the independent model of
+tests/bam_util.py with the CPU oracle's call_umi as the aligner.  The reference's own BAM fixtures are git-LFS pointers in
+this checkout: the composition is checked against the restatement only (parity unpinned)."""
+import gzip
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bam_util
+from oracle import oracle as ora
+from test_bam_cpu import make_records
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+nim = importlib.import_module("nimble-aligner_amd")
+synth = importlib.import_module("nimble-aligner_amd.synth")
+HEADERS = ["reference_genome", "sequence_name", "nt_length", "sequence"]
+
+
+def build(tmp_path, seed, **cfg_over):
+    rng = np.random.default_rng(seed)
+    names, seqs = synth.make_library(24)
+    obj = synth.library_json(names, seqs)
+    obj[0].update(score_percent=0.2, score_threshold=25, **cfg_over)
+    path = str(tmp_path / "lib.json")
+    json.dump(obj, open(path, "w"))
+
+    def seq_of(L):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        st = int(rng.integers(0, len(s) - L))
+        r = list(s[st:st + L])
+        if rng.random() < 0.3:
+            r[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.1:
+            r = list("ACGT"[i] for i in rng.integers(0, 4, size=L))      # a read from nowhere
+        return "".join(r)
+
+    recs = make_records(rng, n_umis=150, seq_of=seq_of)
+    # copies of a pair inside one UMI group with OTHER qualities: one key, last one decides (align.rs:591-600,685)
+    extra = []
+    for r in recs:
+        extra.append(r)
+    bam = str(tmp_path / "in.bam")
+    bam_util.write_bam(bam, extra, block=20000)
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    cfg = ora.config_from_json(obj[0], len(names), "unstranded")
+    return path, bam, extra, ref, cfg
+
+
+@pytest.mark.parametrize("force,over", [(False, {}), (True, {}), (False, {"require_valid_pair": True, "num_mismatches": 1})])
+def test_bam_pipeline_equals_the_model(tmp_path, force, over, monkeypatch):
+    path, bam, recs, ref, cfg = build(tmp_path, 11 + int(force), **over)
+    monkeypatch.setenv("NIMBLE_BAM_BATCH", "64")                 # several device calls, groups never split
+    lib = nim.Library(path, "unstranded").build_index()
+    out = str(tmp_path / "out.tsv.gz")
+    nim.bam_process(bam, [lib], [out], cores=2, force_bam_paired=force)
+    text = gzip.open(out, "rb").read().decode("latin-1")
+    groups = bam_util.model_groups(recs, force)
+    inp = bam_util.call_inputs(groups)
+    assert len(inp["seg"]) > 100
+    exp = ora.call_umi(ora.Index.from_reference(ref), ref, cfg, inp["r1"], inp["o1"], inp["r2"], inp["o2"], q1=inp["q1"],
+                       q2=inp["q2"], skip1=inp["skip1"], skip2=inp["skip2"], segment=inp["seg"], keep_per_read=True)
+    n = bam_util.check_output(text, groups, inp, exp)
+    assert n > 50
+    if not force:
+        assert int(inp["skip1"].sum()) > 5                       # dummies of unpaired reads went through SKIP_ALIGN
+    if over:
+        assert "Required Valid Pair Not Matching" in text
+
+
+def test_cli_takes_a_bam_file(tmp_path):
+    path, bam, recs, ref, cfg = build(tmp_path, 21)
+    exe = os.path.join(ROOT, "nimble-aligner_amd", "lib", "nimble")
+    out = str(tmp_path / "cli.tsv.gz")
+    cp = subprocess.run([exe, "-r", path, "-o", out, "-i", bam, "-c", "4", "-f", "unstranded"], capture_output=True, text=True,
+                        timeout=300)
+    assert cp.returncode == 0, cp.stderr
+    assert "Processing as BAM file" in cp.stdout and "Validation successful" in cp.stdout
+    text = gzip.open(out, "rb").read().decode("latin-1")
+    groups = bam_util.model_groups(recs, False)
+    inp = bam_util.call_inputs(groups)
+    exp = ora.call_umi(ora.Index.from_reference(ref), ref, cfg, inp["r1"], inp["o1"], inp["r2"], inp["o2"], q1=inp["q1"],
+                       q2=inp["q2"], skip1=inp["skip1"], skip2=inp["skip2"], segment=inp["seg"], keep_per_read=True)
+    assert bam_util.check_output(text, groups, inp, exp) > 50
