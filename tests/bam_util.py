@@ -205,6 +205,9 @@ def check_output(text, groups, inputs, oracle_result):
     """The gzip TSV of process::bam::process against the model: header; per sent group the oracle's (callset, count) rows in
     callset order, each standing on a pair of the group, then one empty row per pair whose QNAME stands for no callset; the
     filter columns = the records of the LAST pair with the same read key in the group (align.rs:591-600)."""
+    if not oracle_result.rows:
+        assert text == ""          # the header goes out with the first row (process/bam.rs:86-101)
+        return 0
     lines = text.split("\n")
     assert lines[0] == header()
     assert lines[-1] == ""

@@ -12,7 +12,7 @@ import bam_util
 nim = importlib.import_module("nimble-aligner_amd")
 
 
-def make_records(rng, n_umis=40, seq_of=None, orphan_only_umi=False):
+def make_records(rng, n_umis=40, seq_of=None, orphan_only_umi=False, good_quals=False):
     """10x-like records: runs of one UMI, several cells per UMI in scrambled order, mates adjacent; plus everything the
     reader has to cope with (unpaired reads, orphans, the poly-A UMI, records without CB / with UR only, reverse strand,
     124-base reads that get clipped, N bases, integer tags)."""
@@ -40,7 +40,7 @@ def make_records(rng, n_umis=40, seq_of=None, orphan_only_umi=False):
             if rng.random() < 0.03:
                 del tags["CB"]
             mk = lambda flag, **kw: dict(qname="q%05d" % qn, flag=flag, seq=(seq_of(L) if seq_of else rnd(L)),
-                                         qual=bytes(rng.integers(2, 42, size=L).astype(np.uint8)), tags=dict(tags),
+                                         qual=bytes(rng.integers(36 if good_quals else 2, 42, size=L).astype(np.uint8)), tags=dict(tags),
                                          pos=int(rng.integers(0, 9000)), mpos=int(rng.integers(0, 9000)),
                                          tlen=int(rng.integers(-500, 500)), mapq=int(rng.integers(0, 256)), **kw)
             if kind < 0.70:        # a proper pair, mates adjacent; either may be on the reverse strand
