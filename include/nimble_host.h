@@ -150,6 +150,8 @@ int nimble_bam_process(const char *input, int n_libs, nimble_library *const *lib
                        int force_bam_paired);
 /* The UMI groups of a BAM file as the reference's UMIReader yields them, as text (needs no GPU; see host_capi.cpp). */
 int nimble_host_bam_dump(const char *input, int force_bam_paired, const char *out_path);
+/* The parallel gzip decoder of the FASTQ reader on its own (diagnostic): the decompressed stream written to out_path. */
+int nimble_host_pgzip_decompress(const char *path, int threads, const char *out_path, uint64_t *n_pieces);
 /* process/bam.rs:407-423 */
 int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap);
 int nimble_host_parse_str_as_bool(const char *v, int *out);

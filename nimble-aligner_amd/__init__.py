@@ -471,7 +471,7 @@ HOST_SYMBOLS = [
     "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
     "nimble_fastq_process_sharded", "nimble_bam_process", "nimble_host_bam_dump", "nimble_host_reverse_comp_if_needed",
-    "nimble_host_parse_str_as_bool",
+    "nimble_host_parse_str_as_bool", "nimble_host_pgzip_decompress",
 ]
 
 
@@ -562,6 +562,7 @@ def host_lib():
         L.nimble_host_bam_dump.argtypes = [cp, i32, cp]
         L.nimble_host_reverse_comp_if_needed.argtypes = [cp, i32, cp, u64]
         L.nimble_host_parse_str_as_bool.argtypes = [cp, C.POINTER(i32)]
+        L.nimble_host_pgzip_decompress.argtypes = [cp, i32, cp, C.POINTER(u64)]
         L.nimble_write_to_tsv.argtypes = [vp, cp]
         L.nimble_host_coerce.argtypes = [vp, i32, vp, i32, i32, vp, i32, cp, i32]
         L.nimble_host_natural_lexical_cmp.argtypes = [cp, cp]
@@ -1017,6 +1018,13 @@ def bam_umi_groups(input_file, force_bam_paired=False):
     return groups
 
 
+def pgzip_decompress(path, out_path, threads=4):
+    """The parallel inflate alone: writes the decompressed stream, returns the number of pieces it came in."""
+    k = C.c_uint64(0)
+    _hcheck(host_lib().nimble_host_pgzip_decompress(os.fsencode(path), threads, os.fsencode(out_path), C.byref(k)))
+    return k.value
+
+
 def reverse_comp_if_needed(seq, reverse_comp):
     out = C.create_string_buffer(len(seq) + 8)
     _hcheck(host_lib().nimble_host_reverse_comp_if_needed(seq.encode(), int(reverse_comp), out, len(out)))
@@ -1054,11 +1062,12 @@ def read_fastq_stats(path):
     return n.value, b.value, m.value
 
 
-def read_fastq_batched_stats(path, batch_reads):
-    """The pipeline's threaded batch reader run to the end: (records, bases, max_len, batches, checksum)."""
+def read_fastq_batched_stats(path, batch_reads, checksum=True):
+    """The pipeline's threaded batch reader run to the end: (records, bases, max_len, batches, checksum).  The checksum
+    is a serial pass over every base; `checksum=False` leaves it out (0) when the reader itself is being timed."""
     n, b, m, nb, h = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
     _hcheck(host_lib().nimble_host_read_fastq_batched(os.fsencode(path), batch_reads, C.byref(n), C.byref(b),
-                                                      C.byref(m), C.byref(nb), C.byref(h)))
+                                                      C.byref(m), C.byref(nb), C.byref(h) if checksum else None))
     return n.value, b.value, m.value, nb.value, h.value
 
 

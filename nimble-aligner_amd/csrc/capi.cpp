@@ -130,6 +130,7 @@ struct nimble_ctx {
   hipEvent_t ev_h2d[2] = {}, ev_used[2] = {};
   bool stage_busy[2] = {false, false};
   int stage_k = 0;
+  int h2d_pending = -1;  // staging slot whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
@@ -922,6 +923,7 @@ int nimble_ctx_synchronize(nimble_ctx *c) {
 // stage the read buffers on the device when they are handed over as host memory
 static int stage_inputs(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                         const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  if (mem == NIMBLE_MEM_HOST_PINNED) mem = NIMBLE_MEM_HOST;  // outside a stream the copy is simply waited for
   c->in_r[0] = r1;
   c->in_r[1] = r2;
   c->in_off[0] = r1_off;
@@ -966,7 +968,8 @@ static int check_read_args(const uint8_t *r1, const uint64_t *r1_off, const uint
   if (!r1_off && fixed_len > max_len) max_len = fixed_len;
   if (max_len == 0) max_len = 1;
   if (max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call: max_len above 65535 is not supported");
-  if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE) return fail(NIMBLE_E_INVALID, "nimble_call: bad mem");
+  if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE && mem != NIMBLE_MEM_HOST_PINNED)
+    return fail(NIMBLE_E_INVALID, "nimble_call: bad mem");
   return NIMBLE_OK;
 }
 
@@ -1478,6 +1481,7 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   c->stream_max_len = max_len;
   c->stage_busy[0] = c->stage_busy[1] = false;
   c->stage_k = 0;
+  c->h2d_pending = -1;
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->defer.active = false;
   c->defer.world = 0;
@@ -1510,6 +1514,12 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   const uint8_t *in_r[2] = {r1, r2};
   const uint64_t *in_off[2] = {r1_off, r2_off};
   const int k = c->stage_k;
+  const bool lazy = mem == NIMBLE_MEM_HOST_PINNED;
+  if (c->h2d_pending >= 0) {  // the batch before this one has left its page-locked buffers by now (or is waited for)
+    HIPCHK(hipEventSynchronize(c->ev_h2d[c->h2d_pending]));
+    c->h2d_pending = -1;
+  }
+  if (lazy) mem = NIMBLE_MEM_HOST;
   if (mem == NIMBLE_MEM_HOST) {
     // device staging slot k: wait until the pack kernel that read it last has run, copy on the side stream
     // (overlaps the kernels of the previous batch), let the launch stream wait for the copy
@@ -1570,7 +1580,10 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   }
   launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
   HIPCHK(hipGetLastError());
-  if (mem == NIMBLE_MEM_HOST) HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
+  if (mem == NIMBLE_MEM_HOST) {
+    if (lazy) c->h2d_pending = k;                      // waited for by the next append / the end of the stream
+    else HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
+  }
   c->stream_n += m;
   return NIMBLE_OK;
 }
@@ -1579,6 +1592,10 @@ int nimble_stream_end(nimble_ctx *c) {
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_end: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_end: no streamed call is open");
   HIPCHK(hipSetDevice(c->ix->device));
+  if (c->h2d_pending >= 0) {
+    HIPCHK(hipEventSynchronize(c->ev_h2d[c->h2d_pending]));
+    c->h2d_pending = -1;
+  }
   c->streaming = false;
   c->cb.n = c->stream_n;
   c->cb.key_stride = c->stream_cap;

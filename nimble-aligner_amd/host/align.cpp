@@ -524,7 +524,8 @@ void CallStream::append(const ReadBatch &seqs, const ReadBatch *mates) {
     throw Panic("Error -- read and reverse read files do not have matching lengths: ");
   check_rc(nimble_stream_append(index_.ctx(), seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                                 mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len,
-                                seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
+                                seqs.device ? NIMBLE_MEM_DEVICE
+                                            : (seqs.pinned && (!mates || mates->pinned) ? NIMBLE_MEM_HOST_PINNED : NIMBLE_MEM_HOST)),
            "nimble_stream_append");
   n_ += seqs.n;
 }

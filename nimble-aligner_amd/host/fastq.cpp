@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <atomic>
 #include <exception>
 #include <map>
 #include <algorithm>
@@ -193,6 +194,21 @@ void BatchReader::Batch::unpin() {
 class ParallelPlain {
  public:
   typedef BatchReader::Batch Batch;
+  // batches shared by the parsers of successive memory windows (a compressed file comes in windows)
+  struct Pool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<Batch>> free;
+  };
+  // the same parser over a window of memory [d + from, d + n): `final` = the input ends with it; otherwise the record that
+  // runs into the end of the window is left alone (carry_from() says where it starts) and no batch is the last
+  ParallelPlain(const uint8_t *d, size_t from, size_t n, bool is_mate, bool final, std::shared_ptr<Pool> pool)
+      : is_mate_(is_mate), final_(final), shared_(std::move(pool)) {
+    data_ = d;
+    size_ = n;
+    base_ = from;
+    true_start_ = from;
+    start_workers();
+  }
   ParallelPlain(const std::string &path, bool is_mate) : is_mate_(is_mate) {
     fd_ = open(path.c_str(), O_RDONLY);
     if (fd_ < 0) throw Panic("Error -- could not determine compression format for " + path);
@@ -211,11 +227,16 @@ class ParallelPlain {
       data_ = (const uint8_t *)m;
       (void)madvise(m, size_, MADV_SEQUENTIAL);
     }
+    mapped_ = data_ != nullptr;
+    start_workers();
+  }
+  void start_workers() {
     chunk_ = 8u << 20;
     if (const char *e = getenv("NIMBLE_FASTQ_CHUNK")) chunk_ = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 64);
-    n_chunks_ = size_ ? (size_ + chunk_ - 1) / chunk_ : 1;
+    const size_t span = size_ - base_;
+    n_chunks_ = span ? (span + chunk_ - 1) / chunk_ : 1;
     unsigned t = std::thread::hardware_concurrency();
-    t = t ? std::min(t, 8u) : 4u;
+    t = t ? std::min(t, 16u) : 4u;
     if (const char *e = getenv("NIMBLE_FASTQ_THREADS")) t = (unsigned)std::max(1, atoi(e));
     t = (unsigned)std::min<size_t>(t, n_chunks_);
     window_ = 2 * (size_t)t + 1;
@@ -229,9 +250,10 @@ class ParallelPlain {
     }
     cv_.notify_all();
     for (auto &w : workers_) w.join();
-    if (data_) munmap((void *)data_, size_);
+    if (mapped_) munmap((void *)data_, size_);
     if (fd_ >= 0) close(fd_);
   }
+  size_t carry_from() const { return true_start_; }  // (after the last batch) where the unparsed tail of the window starts
   static bool is_plain(const std::string &path) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;  // the gzip path reports the failure
@@ -257,7 +279,7 @@ class ParallelPlain {
     b->pin();
     true_start_ = b->end;
     b->raw_offset = b->end;
-    b->last = !b->error.empty() || c + 1 == n_chunks_;
+    b->last = !b->error.empty() || (final_ && c + 1 == n_chunks_);
     {
       std::lock_guard<std::mutex> lk(mu_);
       ++delivered_;
@@ -267,13 +289,25 @@ class ParallelPlain {
   }
   bool done() const { return delivered_ >= n_chunks_; }
   void recycle(std::unique_ptr<Batch> b) {
+    if (shared_) {
+      std::lock_guard<std::mutex> lk(shared_->mu);
+      shared_->free.push_back(std::move(b));
+      return;
+    }
     std::lock_guard<std::mutex> lk(mu_);
     pool_.push_back(std::move(b));
   }
 
  private:
   std::unique_ptr<Batch> take() {
-    {
+    if (shared_) {
+      std::lock_guard<std::mutex> lk(shared_->mu);
+      if (!shared_->free.empty()) {
+        std::unique_ptr<Batch> b = std::move(shared_->free.back());
+        shared_->free.pop_back();
+        return b;
+      }
+    } else {
       std::lock_guard<std::mutex> lk(mu_);
       if (!pool_.empty()) {
         std::unique_ptr<Batch> b = std::move(pool_.back());
@@ -287,7 +321,7 @@ class ParallelPlain {
     return b;
   }
 
-  size_t chunk_end(size_t c) const { return std::min(size_, (c + 1) * chunk_); }
+  size_t chunk_end(size_t c) const { return std::min(size_, base_ + (c + 1) * chunk_); }
 
   // first record start at or after `from`: a line starting with '@' whose next-but-one line starts with '+'
   size_t guess_start(size_t from, size_t limit) const {
@@ -321,11 +355,25 @@ class ParallelPlain {
     b.error.clear();
     b.start = start;
     MemLines ln(data_, start, size_);
+    size_t rec = start;  // where the record being read starts
     try {
-      while (ln.pos() < limit && read_record(ln, b.data, malformed_text(is_mate_))) {
+      while (ln.pos() < limit) {
+        rec = ln.pos();
+        if (!read_record(ln, b.data, malformed_text(is_mate_))) break;
+        if (!final_ && ln.pos() >= size_) {
+          // the record reaches the end of a window that is not the end of the input: it may go on in the next one
+          b.data.offsets.pop_back();
+          b.data.bases.resize(b.data.offsets.back());
+          b.end = rec;
+          return;
+        }
       }
     } catch (const Panic &e) {
       b.data.bases.resize(b.data.offsets.back());
+      if (!final_ && ln.pos() >= size_) {  // the lines ran out inside the record: the next window has the rest
+        b.end = rec;
+        return;
+      }
       b.error = e.what();
     }
     b.end = std::max(ln.pos(), start);
@@ -342,8 +390,8 @@ class ParallelPlain {
         c = claimed_++;
       }
       std::unique_ptr<Batch> b = take();
-      const size_t lo = c * chunk_, hi = chunk_end(c);
-      parse_range(c == 0 ? 0 : guess_start(lo, hi), hi, *b);
+      const size_t lo = base_ + c * chunk_, hi = chunk_end(c);
+      parse_range(c == 0 ? base_ : guess_start(lo, hi), hi, *b);
       {
         std::lock_guard<std::mutex> lk(mu_);
         results_[c] = std::move(b);
@@ -353,9 +401,11 @@ class ParallelPlain {
   }
 
   bool is_mate_;
+  bool final_ = true, mapped_ = false;
+  std::shared_ptr<Pool> shared_;
   int fd_ = -1;
   const uint8_t *data_ = nullptr;
-  size_t size_ = 0, chunk_ = 0, n_chunks_ = 0, window_ = 0;
+  size_t size_ = 0, base_ = 0, chunk_ = 0, n_chunks_ = 0, window_ = 0;
   std::vector<std::unique_ptr<Batch>> results_, pool_;
   std::vector<std::thread> workers_;
   std::mutex mu_;
@@ -364,9 +414,198 @@ class ParallelPlain {
   bool stop_ = false;
 };
 
+// ---- gzip files: the stream is inflated by many threads (pgzip.cpp) into windows of memory, each window parsed like a
+// mapped plain file; the record that straddles two windows is carried over -------------------------------------------
+class ParallelGz {
+ public:
+  typedef BatchReader::Batch Batch;
+  ParallelGz(const std::string &path, bool is_mate) : is_mate_(is_mate), pool_(new ParallelPlain::Pool()) {
+    unsigned t = std::thread::hardware_concurrency();
+    t = t ? std::min(t, 32u) : 4u;
+    if (const char *e = getenv("NIMBLE_GZIP_THREADS")) t = (unsigned)std::max(1, atoi(e));
+    threads_ = t;
+    target_ = 256u << 20;
+    if (const char *e = getenv("NIMBLE_GZIP_WINDOW")) target_ = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1u << 16);
+    gz_.reset(new pgzip::Reader(path, t));
+    producer_ = std::thread([this] { produce(); });
+  }
+  ~ParallelGz() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (producer_.joinable()) producer_.join();
+  }
+  std::unique_ptr<Batch> next() {
+    for (;;) {
+      if (!cur_) {
+        std::unique_ptr<Window> w;
+        {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_.wait(lk, [&] { return !windows_.empty(); });
+          w = std::move(windows_.front());
+          windows_.pop_front();
+        }
+        cv_.notify_all();
+        if (!w->error.empty()) throw Panic(w->error);
+        // the unparsed tail of the window before goes in front of this one's data (there is headroom for it)
+        if (carry_.size() > w->head) {  // (a record longer than the headroom: move the window's data up)
+          pgzip::HugeBuf<uint8_t> nb;
+          const size_t body = w->buf.size() - w->head;
+          nb.resize(carry_.size() + body);
+          memcpy(nb.data() + carry_.size(), w->buf.data() + w->head, body);
+          w->buf = std::move(nb);
+          w->head = carry_.size();
+        }
+        memcpy(w->buf.data() + w->head - carry_.size(), carry_.data(), carry_.size());
+        const size_t from = w->head - carry_.size();
+        win_ = std::move(w);
+        cur_.reset(new ParallelPlain(win_->buf.data(), from, win_->buf.size(), is_mate_, win_->final, pool_));
+      }
+      if (!cur_->done()) {
+        std::unique_ptr<Batch> b = cur_->next();
+        raw_ += 1;
+        return b;
+      }
+      const size_t cf = cur_->carry_from();
+      carry_.assign(win_->buf.data() + std::min(cf, win_->buf.size()), win_->buf.data() + win_->buf.size());
+      const bool was_final = win_->final;
+      cur_.reset();
+      {
+        std::lock_guard<std::mutex> lk(mu_);  // the window's memory goes round
+        if (spare_.size() < 3) spare_.push_back(std::move(win_));
+      }
+      win_.reset();
+      if (was_final) return nullptr;  // (not reached: the final window's last batch has `last` set)
+    }
+  }
+  void recycle(std::unique_ptr<Batch> b) {
+    std::lock_guard<std::mutex> lk(pool_->mu);
+    pool_->free.push_back(std::move(b));
+  }
+
+ private:
+  struct Window {
+    pgzip::HugeBuf<uint8_t> buf;
+    size_t head = 0;  // the data starts here; the space in front takes the carried tail of the previous window
+    bool final = false;
+    std::string error;
+  };
+  // pieces -> windows: the pieces of a window are resolved to bytes and CRC-checked by a thread each
+  void produce() {
+    uint32_t crc = 0;
+    uint64_t member_len = 0;
+    bool more = true;
+    try {
+      while (more) {
+        std::vector<pgzip::Piece> pieces;
+        size_t total = 0;
+        while (total < target_) {
+          pgzip::Piece p;
+          if (!gz_->next(p)) {
+            more = false;
+            break;
+          }
+          total += p.size();
+          pieces.push_back(std::move(p));
+        }
+        std::unique_ptr<Window> w;
+        {
+          std::lock_guard<std::mutex> lk(mu_);
+          if (!spare_.empty()) {
+            w = std::move(spare_.back());
+            spare_.pop_back();
+          }
+        }
+        if (!w) w.reset(new Window());
+        w->head = 1u << 16;
+        w->buf.resize(w->head + total);
+        w->final = !more;
+        std::vector<size_t> at(pieces.size() + 1, w->head);
+        for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].size();
+        // per piece: the CRC of each stretch between member ends (combined in order below)
+        std::vector<std::vector<uint32_t>> part(pieces.size());
+        std::vector<std::thread> th;
+        std::atomic<size_t> nextp{0};
+        auto body = [&] {
+          for (size_t k = nextp++; k < pieces.size(); k = nextp++) {
+            uint8_t *o = w->buf.data() + at[k];
+            pgzip::resolve(pieces[k], o);
+            size_t from = 0;
+            const pgzip::Piece &p = pieces[k];
+            for (size_t m = 0; m <= p.member_ends.size(); ++m) {
+              const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : p.size();
+              uint32_t c = 0;
+              for (size_t q = from; q < to;) {
+                const size_t step = std::min<size_t>(to - q, 1u << 30);
+                c = (uint32_t)crc32(c, o + q, (uInt)step);
+                q += step;
+              }
+              part[k].push_back(c);
+              from = to;
+            }
+            gz_->recycle(std::move(pieces[k].sym));
+          }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(threads_, std::max<size_t>(pieces.size(), 1));
+        for (unsigned i = 0; i < nt; ++i) th.emplace_back(body);
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < pieces.size(); ++k) {
+          const pgzip::Piece &p = pieces[k];
+          const size_t psize = at[k + 1] - at[k];  // (the symbols are gone by now)
+          size_t from = 0;
+          for (size_t m = 0; m <= p.member_ends.size(); ++m) {
+            const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : psize;
+            crc = (uint32_t)crc32_combine(crc, part[k][m], (z_off_t)(to - from));
+            member_len += to - from;
+            if (m < p.member_ends.size()) {
+              if (crc != p.member_crc[m] || (uint32_t)member_len != p.member_isize[m])
+                throw Panic("Error -- could not determine compression format (gzip member fails its CRC-32 / length check)");
+              crc = 0;
+              member_len = 0;
+            }
+            from = to;
+          }
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || windows_.size() < 2; });
+        if (stop_) return;
+        windows_.push_back(std::move(w));
+        lk.unlock();
+        cv_.notify_all();
+      }
+    } catch (const std::exception &e) {
+      std::unique_ptr<Window> w(new Window());
+      w->error = e.what();
+      w->final = true;
+      std::lock_guard<std::mutex> lk(mu_);
+      windows_.push_back(std::move(w));
+      cv_.notify_all();
+    }
+  }
+
+  bool is_mate_;
+  std::shared_ptr<ParallelPlain::Pool> pool_;
+  unsigned threads_ = 1;
+  size_t target_ = 0;
+  std::unique_ptr<pgzip::Reader> gz_;
+  std::thread producer_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::unique_ptr<Window>> windows_;
+  std::vector<std::unique_ptr<Window>> spare_;  // windows parsed to the end: their memory takes the next one
+  bool stop_ = false;
+  std::unique_ptr<Window> win_;
+  std::unique_ptr<ParallelPlain> cur_;
+  std::vector<uint8_t> carry_;
+  uint64_t raw_ = 0;
+};
+
 // ---- batch reader: a thread parses ahead, batches are handed over in file order ----------------------
 struct BatchReader::Impl {
   std::unique_ptr<ParallelPlain> plain;  // plain files: chunk-parallel parse (then no reader thread of our own)
+  std::unique_ptr<ParallelGz> gz;        // gzip files: parallel inflate into windows, each parsed the same way
   std::string path;
   bool is_mate;
   size_t batch_reads;
@@ -440,6 +679,11 @@ BatchReader::BatchReader(const std::string &path, bool is_mate, size_t batch_rea
     impl_->plain.reset(new ParallelPlain(path, is_mate));
     return;
   }
+  const bool serial_gz = getenv("NIMBLE_GZIP_SERIAL") != nullptr;
+  if (!serial && !serial_gz) {
+    impl_->gz.reset(new ParallelGz(path, is_mate));
+    return;
+  }
   for (int i = 0; i < 3; ++i) impl_->spare.emplace_back(new Batch());
   impl_->th = std::thread([this] { impl_->run(); });
 }
@@ -455,6 +699,7 @@ BatchReader::~BatchReader() {
 
 std::unique_ptr<BatchReader::Batch> BatchReader::next() {
   if (impl_->plain) return impl_->plain->next();
+  if (impl_->gz) return impl_->gz->next();
   std::unique_lock<std::mutex> lk(impl_->mu);
   impl_->cv.wait(lk, [&] { return !impl_->ready.empty(); });
   std::unique_ptr<Batch> b = std::move(impl_->ready.front());
@@ -467,6 +712,10 @@ std::unique_ptr<BatchReader::Batch> BatchReader::next() {
 void BatchReader::recycle(std::unique_ptr<Batch> b) {
   if (impl_->plain) {
     impl_->plain->recycle(std::move(b));
+    return;
+  }
+  if (impl_->gz) {
+    impl_->gz->recycle(std::move(b));
     return;
   }
   std::lock_guard<std::mutex> lk(impl_->mu);
@@ -497,13 +746,17 @@ uint64_t file_size(const std::string &p) {
 struct Cursor {
   parse::fastq::BatchReader rd;
   std::unique_ptr<parse::fastq::BatchReader::Batch> b;
+  // the batch before the current one: its copy to the device may still run (NIMBLE_MEM_HOST_PINNED: buffers stay untouched
+  // until the NEXT append has returned), so it goes back to the reader one step late
+  std::unique_ptr<parse::fastq::BatchReader::Batch> held;
   uint64_t used = 0;
   Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads) {}
   uint64_t avail() const { return b ? b->data.n() - used : 0; }
   bool at_end() const { return b && b->last && used == b->data.n(); }  // the file's event (EOF or bad record) is next
   void fill() {  // make records available unless the file is at its event
     while (!b || (used == b->data.n() && !b->last)) {
-      if (b) rd.recycle(std::move(b));
+      if (held) rd.recycle(std::move(held));
+      held = std::move(b);
       b = rd.next();
       used = 0;
     }
@@ -548,11 +801,13 @@ void streamed(const std::vector<std::string> &input_files,
       a.offsets = c1.b->data.offsets.data() + c1.used;
       a.n = n;
       a.max_len = c1.b->data.max_len;
+      a.pinned = c1.b->pinned[0] != nullptr;  // (the small offsets array may be pageable: HIP stages such a copy before it returns)
       if (paired) {
         m.bases = c2->b->data.bases.data();
         m.offsets = c2->b->data.offsets.data() + c2->used;
         m.n = n;
         m.max_len = c2->b->data.max_len;
+        m.pinned = c2->b->pinned[0] != nullptr;
       }
       for (auto &st : streams) st->append(a, paired ? &m : nullptr);
       c1.used += n;

@@ -483,6 +483,32 @@ int nimble_host_bam_dump(const char *input, int force_bam_paired, const char *ou
   });
 }
 
+// The parallel inflate on its own (host/pgzip.cpp): the decompressed stream of a gzip file written to out_path, pieces
+// resolved in order.  Diagnostic and test surface; no CRC check here (the FASTQ reader makes it).
+int nimble_host_pgzip_decompress(const char *path, int threads, const char *out_path, uint64_t *n_pieces) {
+  return guarded([&] {
+    parse::pgzip::Reader rd(path, (unsigned)std::max(threads, 1));
+    FILE *f = fopen(out_path, "wb");
+    if (!f) throw Panic("nimble_host_pgzip_decompress: cannot write the output file");
+    parse::pgzip::Piece p;
+    std::vector<uint8_t> buf;
+    uint64_t k = 0;
+    try {
+      while (rd.next(p)) {
+        buf.resize(p.size());
+        parse::pgzip::resolve(p, buf.data());
+        fwrite(buf.data(), 1, buf.size(), f);
+        ++k;
+      }
+    } catch (...) {
+      fclose(f);
+      throw;
+    }
+    fclose(f);
+    if (n_pieces) *n_pieces = k;
+  });
+}
+
 int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap) {
   return guarded([&] {
     const std::string r = process::bam::reverse_comp_if_needed(seq, reverse_comp != 0);
@@ -565,7 +591,7 @@ int nimble_host_read_fastq_batched(const char *path, uint64_t batch_reads, uint6
       *bases += b->data.bases.size();
       *max_len = std::max(*max_len, b->data.max_len);
       ++*n_batches;
-      for (uint64_t i = 0; i < b->data.n(); ++i) {  // FNV over (length, bases) of every record, in order
+      for (uint64_t i = 0; checksum && i < b->data.n(); ++i) {  // FNV over (length, bases) of every record, in order
         h = (h ^ (b->data.offsets[i + 1] - b->data.offsets[i])) * 1099511628211ULL;
         for (uint64_t k = b->data.offsets[i]; k < b->data.offsets[i + 1]; ++k)
           h = (h ^ b->data.bases[k]) * 1099511628211ULL;

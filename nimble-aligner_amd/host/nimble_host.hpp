@@ -11,7 +11,10 @@
 //   nimble::process::fastq     <-  src/process/fastq.rs
 // Rust panics become nimble::Panic exceptions carrying the reference's message text.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <new>
 #include <map>
 #include <chrono>
 #include <memory>
@@ -160,6 +163,7 @@ struct ReadBatch {
   uint32_t fixed_len = 0;
   uint32_t max_len = 0;
   bool device = false;
+  bool pinned = false;  // page-locked host buffers the caller keeps untouched until the next append has returned
 };
 
 // One row of the result: (callset, (count, metadata, metadata)); metadata is empty on the FASTQ path
@@ -331,6 +335,96 @@ class BatchReader {
   std::unique_ptr<Impl> impl_;
 };
 }  // namespace fastq
+namespace pgzip {
+// One gzip stream inflated by many threads (host/pgzip.cpp): pieces of the decompressed stream in order, each as 16-bit
+// symbols -- a value below 256 is a byte, 256 + k is byte k of the 32 KiB `window` in front of the piece -- so that the
+// expensive part of turning them into bytes runs in parallel too (resolve), with the member trailers for the CRC check.
+// A large array that is written once and read once: anonymous memory on 2 MiB pages where the kernel grants them, never
+// zero-filled by us, never copied on growth below its reservation.  (std::vector costs a page fault per 4 KiB of fresh
+// memory and a memset on resize(); with a dozen threads filling such arrays at once the faults serialise in the kernel
+// and the first pass over new memory ran ten times slower than the decoding it was for.)
+template <class T>
+class HugeBuf {
+ public:
+  HugeBuf() = default;
+  ~HugeBuf() { release(); }
+  HugeBuf(HugeBuf &&o) noexcept : map_(o.map_), map_bytes_(o.map_bytes_), p_(o.p_), n_(o.n_), cap_(o.cap_) {
+    o.map_ = nullptr;
+    o.p_ = nullptr;
+    o.map_bytes_ = o.n_ = o.cap_ = 0;
+  }
+  HugeBuf &operator=(HugeBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      new (this) HugeBuf(std::move(o));
+    }
+    return *this;
+  }
+  HugeBuf(const HugeBuf &) = delete;
+  HugeBuf &operator=(const HugeBuf &) = delete;
+  T *data() { return p_; }
+  const T *data() const { return p_; }
+  size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
+  bool empty() const { return n_ == 0; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+  void reserve(size_t cap);           // virtual address space only: untouched pages cost nothing
+  void resize(size_t n) {             // new entries are unspecified (fresh pages read as zero)
+    if (n > cap_) reserve(std::max(n, cap_ * 2));
+    n_ = n;
+  }
+  void release();
+
+ private:
+  void *map_ = nullptr;
+  size_t map_bytes_ = 0;
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+void *huge_map(size_t bytes, void **map, size_t *map_bytes);  // 2 MiB aligned, MADV_HUGEPAGE; panics when refused
+void huge_unmap(void *map, size_t map_bytes);
+template <class T>
+void HugeBuf<T>::reserve(size_t cap) {
+  if (cap <= cap_) return;
+  void *m = nullptr;
+  size_t mb = 0;
+  T *q = (T *)huge_map(cap * sizeof(T), &m, &mb);
+  if (n_) memcpy(q, p_, n_ * sizeof(T));
+  if (map_) huge_unmap(map_, map_bytes_);
+  map_ = m;
+  map_bytes_ = mb;
+  p_ = q;
+  cap_ = cap;
+}
+template <class T>
+void HugeBuf<T>::release() {
+  if (map_) huge_unmap(map_, map_bytes_);
+  map_ = nullptr;
+  p_ = nullptr;
+  map_bytes_ = n_ = cap_ = 0;
+}
+
+struct Piece {
+  HugeBuf<uint16_t> sym;         // 32768 window placeholders, then the data
+  std::vector<uint8_t> window;   // the 32768 bytes of the stream in front of the piece
+  std::vector<uint64_t> member_ends;              // data positions where a gzip member ended ...
+  std::vector<uint32_t> member_crc, member_isize;  // ... and that member's trailer
+  size_t size() const { return sym.size() - 32768; }
+};
+class Reader {
+ public:
+  Reader(const std::string &path, unsigned threads);
+  ~Reader();
+  bool next(Piece &out);  // false at the end of the stream; panics on corrupt input
+  void recycle(HugeBuf<uint16_t> &&sym);  // a piece's symbol array, done with: the next chunk decodes into it
+  struct Impl;
+ private:
+  std::unique_ptr<Impl> impl_;
+};
+void resolve(const Piece &p, uint8_t *out);  // p.size() bytes
+}  // namespace pgzip
+
 namespace bam {
 // What the reference reads of a BAM record (rust_htslib::bam::Record), decoded from BGZF + BAM with zlib alone.
 struct Record {

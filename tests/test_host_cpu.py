@@ -318,10 +318,16 @@ def test_batched_fastq_reader_matches_whole_file_reader(tmp_path, monkeypatch):
     n, bases, max_len = nim.read_fastq_stats(str(plain))
     assert (n, bases, max_len) == (len(recs), sum(map(len, recs)), max(map(len, recs)))
     want = _fnv_records(recs)
+    monkeypatch.setenv("NIMBLE_GZIP_SERIAL", "1")            # the one-thread zlib reader: batches of exactly `batch`
     for batch in (1, 7, 1000, 4999, 5000, 5001, 1 << 20):
         got = nim.read_fastq_batched_stats(str(gz), batch)
         assert got[:3] == (n, bases, max_len) and got[4] == want
         assert got[3] == len(recs) // batch + 1          # a final (possibly empty) batch closes the file
+    monkeypatch.delenv("NIMBLE_GZIP_SERIAL")
+    # the many-threaded gzip reader (tests/test_pgzip_cpu.py): batches follow its parse chunks, the records do not change
+    for batch in (1, 1000, 1 << 20):
+        got = nim.read_fastq_batched_stats(str(gz), batch)
+        assert got[:3] == (n, bases, max_len) and got[4] == want
     # plain files are parsed in parallel chunks (one batch per chunk); the chunk size must not matter, nor the
     # number of threads, and a chunk boundary may fall anywhere (inside a header, a quality line that starts with '@')
     for chunk, threads in ((64, 3), (100, 1), (997, 8), (4096, 4), (1 << 16, 2), (1 << 30, 4)):
