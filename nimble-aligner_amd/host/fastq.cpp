@@ -498,10 +498,13 @@ class ParallelGz {
     uint64_t member_len = 0;
     bool more = true;
     try {
+      // the first windows are small, so that parsing (and the device) start while most of the file is still being inflated
+      size_t target = std::min<size_t>(target_, 32u << 20);
       while (more) {
         std::vector<pgzip::Piece> pieces;
         size_t total = 0;
-        while (total < target_) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (total < target) {
           pgzip::Piece p;
           if (!gz_->next(p)) {
             more = false;
@@ -510,6 +513,8 @@ class ParallelGz {
           total += p.size();
           pieces.push_back(std::move(p));
         }
+        target = std::min(target_, target * 2);
+        const auto t1 = std::chrono::steady_clock::now();
         std::unique_ptr<Window> w;
         {
           std::lock_guard<std::mutex> lk(mu_);
@@ -531,18 +536,11 @@ class ParallelGz {
         auto body = [&] {
           for (size_t k = nextp++; k < pieces.size(); k = nextp++) {
             uint8_t *o = w->buf.data() + at[k];
-            pgzip::resolve(pieces[k], o);
             size_t from = 0;
             const pgzip::Piece &p = pieces[k];
             for (size_t m = 0; m <= p.member_ends.size(); ++m) {
               const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : p.size();
-              uint32_t c = 0;
-              for (size_t q = from; q < to;) {
-                const size_t step = std::min<size_t>(to - q, 1u << 30);
-                c = (uint32_t)crc32(c, o + q, (uInt)step);
-                q += step;
-              }
-              part[k].push_back(c);
+              part[k].push_back(pgzip::resolve_crc(p, from, to, o, 0));
               from = to;
             }
             gz_->recycle(std::move(pieces[k].sym));
@@ -568,13 +566,21 @@ class ParallelGz {
             from = to;
           }
         }
+        const auto t2 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || windows_.size() < 2; });
         if (stop_) return;
         windows_.push_back(std::move(w));
         lk.unlock();
         cv_.notify_all();
+        const auto t3 = std::chrono::steady_clock::now();
+        t_gather_ += std::chrono::duration<double>(t1 - t0).count();
+        t_resolve_ += std::chrono::duration<double>(t2 - t1).count();
+        t_blocked_ += std::chrono::duration<double>(t3 - t2).count();
       }
+      if (getenv("NIMBLE_GZIP_DEBUG"))
+        fprintf(stderr, "[pgzip] window builder: %.3f s waiting for inflated pieces, %.3f s resolving + CRC, %.3f s blocked on the parser\n",
+                t_gather_, t_resolve_, t_blocked_);
     } catch (const std::exception &e) {
       std::unique_ptr<Window> w(new Window());
       w->error = e.what();
@@ -594,6 +600,7 @@ class ParallelGz {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::unique_ptr<Window>> windows_;
+  double t_gather_ = 0, t_resolve_ = 0, t_blocked_ = 0;
   std::vector<std::unique_ptr<Window>> spare_;  // windows parsed to the end: their memory takes the next one
   bool stop_ = false;
   std::unique_ptr<Window> win_;

@@ -423,6 +423,9 @@ class Reader {
   std::unique_ptr<Impl> impl_;
 };
 void resolve(const Piece &p, uint8_t *out);  // p.size() bytes
+// bytes [from, to) of the piece into out[from .. to), and zlib's crc32 of them continued from `crc`
+uint32_t resolve_crc(const Piece &p, size_t from, size_t to, uint8_t *out, uint32_t crc);
+uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len);  // zlib's crc32, by carry-less multiplication
 }  // namespace pgzip
 
 namespace bam {

@@ -12,6 +12,8 @@ substitutions), 15 % uniform random, 5 % exact duplicates of an earlier read, 3 
 """
 import json
 
+import os
+
 import numpy as np
 
 LIB_SEED = 0x6E696D626C65  # "nimble"
@@ -171,8 +173,11 @@ def write_fastq(path, reads, prefix="r"):
             f.write(b"@" + prefix.encode() + str(i).encode() + b"\n" + reads[i].tobytes() + b"\n+\n" + qual + b"\n")
 
 
-def write_fastq_fast(path, reads, prefix=b"r", chunk=1 << 20):
-    """Vectorised FASTQ writer for large synthetic sets: fixed-width records '@r%010d' / bases / '+' / 'I'*L."""
+def write_fastq_fast(path, reads, prefix=b"r", chunk=1 << 20, qual="const"):
+    """Vectorised FASTQ writer for large synthetic sets: fixed-width records '@r%010d' / bases / '+' / 'I'*L.
+    qual="binned": qualities drawn from four values the way a binning sequencer writes them (mostly 'F', some ':', ',',
+    '#') -- what a gzip stream of real reads spends most of its literals on; a constant quality line compresses to
+    nothing and flatters a gzip reader."""
     n, L = reads.shape
     head = 1 + len(prefix) + 10 + 1
     rec = head + L + 3 + L + 1
@@ -189,9 +194,86 @@ def write_fastq_fast(path, reads, prefix=b"r", chunk=1 << 20):
             out[:, head - 1] = ord("\n")
             out[:, head:head + L] = reads[lo:hi]
             out[:, head + L:head + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-            out[:, head + L + 3:head + 2 * L + 3] = ord("I")
+            if qual == "binned":
+                rng = np.random.default_rng(lo + 17)
+                q = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=(m, L), p=[0.90, 0.06, 0.03, 0.01])]
+                out[:, head + L + 3:head + 2 * L + 3] = q
+            else:
+                out[:, head + L + 3:head + 2 * L + 3] = ord("I")
             out[:, rec - 1] = ord("\n")
             f.write(out.tobytes())
+
+
+def _deflate_part(args):
+    path, lo, hi, level, last = args
+    import zlib
+    with open(path, "rb") as f:
+        f.seek(max(lo - 32768, 0))
+        prime = f.read(lo - max(lo - 32768, 0))
+        data = f.read(hi - lo)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, prime) if prime else \
+        zlib.compressobj(level, zlib.DEFLATED, -15, 9)
+    return c.compress(data) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(data), len(data)
+
+
+def gzip_single_stream(src, dst, level=6, part=32 << 20, workers=None):
+    """`src` compressed into ONE gzip member by many processes (the way pigz does it: each part is deflated with the 32 KiB
+    before it as its dictionary and closed with a sync flush, so the parts concatenate into a single deflate stream whose
+    back-references cross the seams).  For large synthetic .fastq.gz inputs, where `gzip` itself would take minutes."""
+    import multiprocessing as mp
+    import struct
+    import zlib
+    size = os.path.getsize(src)
+    cuts = list(range(0, size, part)) + [size]
+    jobs = [(src, cuts[i], cuts[i + 1], level, i + 2 == len(cuts)) for i in range(len(cuts) - 1)]
+    if not jobs:
+        jobs = [(src, 0, 0, level, True)]
+    workers = workers or min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 32)
+    crc, total = 0, 0
+    with mp.get_context("fork").Pool(workers) as pool, open(dst, "wb") as out:
+        out.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        for blob, c, n in pool.imap(_deflate_part, jobs):
+            out.write(blob)
+            crc = _crc32_combine(crc, c, n)
+            total += n
+        out.write(struct.pack("<II", crc & 0xFFFFFFFF, total & 0xFFFFFFFF))
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (python's zlib does not export it): crc of A+B from crc(A), crc(B), len(B) -- multiplication
+    by x^(8 len2) modulo the CRC polynomial, on GF(2) matrices."""
+    if len2 == 0:
+        return crc1
+
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[i]) for i in range(32)]
+
+    odd = [0xEDB88320] + [1 << i for i in range(31)]  # the operator for one zero bit
+    even = square(odd)    # two
+    odd = square(even)    # four
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
 
 
 def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 << 20):
