@@ -235,8 +235,7 @@ class ParallelPlain {
     if (const char *e = getenv("NIMBLE_FASTQ_CHUNK")) chunk_ = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 64);
     const size_t span = size_ - base_;
     n_chunks_ = span ? (span + chunk_ - 1) / chunk_ : 1;
-    unsigned t = std::thread::hardware_concurrency();
-    t = t ? std::min(t, 16u) : 4u;
+    unsigned t = std::min(parse::usable_cpus(), 16u);
     if (const char *e = getenv("NIMBLE_FASTQ_THREADS")) t = (unsigned)std::max(1, atoi(e));
     t = (unsigned)std::min<size_t>(t, n_chunks_);
     window_ = 2 * (size_t)t + 1;
@@ -420,8 +419,7 @@ class ParallelGz {
  public:
   typedef BatchReader::Batch Batch;
   ParallelGz(const std::string &path, bool is_mate) : is_mate_(is_mate), pool_(new ParallelPlain::Pool()) {
-    unsigned t = std::thread::hardware_concurrency();
-    t = t ? std::min(t, 32u) : 4u;
+    unsigned t = std::min(parse::usable_cpus(), 32u);
     if (const char *e = getenv("NIMBLE_GZIP_THREADS")) t = (unsigned)std::max(1, atoi(e));
     threads_ = t;
     target_ = 256u << 20;
@@ -529,43 +527,54 @@ class ParallelGz {
         w->final = !more;
         std::vector<size_t> at(pieces.size() + 1, w->head);
         for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].size();
-        // per piece: the CRC of each stretch between member ends (combined in order below)
-        std::vector<std::vector<uint32_t>> part(pieces.size());
-        std::vector<std::thread> th;
-        std::atomic<size_t> nextp{0};
-        auto body = [&] {
-          for (size_t k = nextp++; k < pieces.size(); k = nextp++) {
-            uint8_t *o = w->buf.data() + at[k];
-            size_t from = 0;
-            const pgzip::Piece &p = pieces[k];
-            for (size_t m = 0; m <= p.member_ends.size(); ++m) {
-              const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : p.size();
-              part[k].push_back(pgzip::resolve_crc(p, from, to, o, 0));
-              from = to;
-            }
-            gz_->recycle(std::move(pieces[k].sym));
-          }
+        // the pieces cut into stretches of at most 2 MiB that end where a gzip member ends; every thread takes stretches
+        // (a piece per thread left most threads idle: a window holds about as many pieces as the decoder has threads, of
+        // very different sizes), their CRCs are combined in order below
+        struct Task {
+          size_t piece, from, to;
+          bool ends_member;
+          uint32_t member;  // index into the piece's member list when ends_member
+          uint32_t crc;
         };
-        const unsigned nt = (unsigned)std::min<size_t>(threads_, std::max<size_t>(pieces.size(), 1));
-        for (unsigned i = 0; i < nt; ++i) th.emplace_back(body);
-        for (auto &t : th) t.join();
+        std::vector<Task> tasks;
+        const size_t STRETCH = 2u << 20;
         for (size_t k = 0; k < pieces.size(); ++k) {
           const pgzip::Piece &p = pieces[k];
-          const size_t psize = at[k + 1] - at[k];  // (the symbols are gone by now)
           size_t from = 0;
           for (size_t m = 0; m <= p.member_ends.size(); ++m) {
-            const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : psize;
-            crc = (uint32_t)crc32_combine(crc, part[k][m], (z_off_t)(to - from));
-            member_len += to - from;
-            if (m < p.member_ends.size()) {
-              if (crc != p.member_crc[m] || (uint32_t)member_len != p.member_isize[m])
-                throw Panic("Error -- could not determine compression format (gzip member fails its CRC-32 / length check)");
-              crc = 0;
-              member_len = 0;
+            const size_t to = m < p.member_ends.size() ? (size_t)p.member_ends[m] : p.size();
+            for (size_t q = from; q < to || q == from; q += STRETCH) {
+              const size_t e = std::min(to, q + STRETCH);
+              tasks.push_back(Task{k, q, e, e == to && m < p.member_ends.size(), (uint32_t)m, 0});
+              if (e == to) break;
             }
             from = to;
           }
         }
+        std::vector<std::thread> th;
+        std::atomic<size_t> nextt{0};
+        auto body = [&] {
+          for (size_t i = nextt++; i < tasks.size(); i = nextt++) {
+            Task &t = tasks[i];
+            t.crc = pgzip::resolve_crc(pieces[t.piece], t.from, t.to, w->buf.data() + at[t.piece], 0);
+          }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(threads_, std::max<size_t>(tasks.size(), 1));
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back(body);
+        body();
+        for (auto &t : th) t.join();
+        for (const Task &t : tasks) {
+          crc = (uint32_t)crc32_combine(crc, t.crc, (z_off_t)(t.to - t.from));
+          member_len += t.to - t.from;
+          if (t.ends_member) {
+            const pgzip::Piece &p = pieces[t.piece];
+            if (crc != p.member_crc[t.member] || (uint32_t)member_len != p.member_isize[t.member])
+              throw Panic("Error -- could not determine compression format (gzip member fails its CRC-32 / length check)");
+            crc = 0;
+            member_len = 0;
+          }
+        }
+        for (auto &p : pieces) gz_->recycle(std::move(p.sym));
         const auto t2 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || windows_.size() < 2; });

@@ -335,6 +335,11 @@ class BatchReader {
   std::unique_ptr<Impl> impl_;
 };
 }  // namespace fastq
+// CPUs this process may really use: the smaller of the affinity mask and the cgroup's CPU quota (a container on a 256-thread
+// host with a quota of 16 CPUs reports 256 from hardware_concurrency(); thread pools sized by that spend the quota on
+// contention and run slower).  At least 1.
+unsigned usable_cpus();
+
 namespace pgzip {
 // One gzip stream inflated by many threads (host/pgzip.cpp): pieces of the decompressed stream in order, each as 16-bit
 // symbols -- a value below 256 is a byte, 256 + k is byte k of the 32 KiB `window` in front of the piece -- so that the

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -34,6 +35,41 @@
 
 namespace nimble {
 namespace parse {
+unsigned usable_cpus() {
+  static const unsigned cached = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (!n) n = 4;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const int c = CPU_COUNT(&set);
+      if (c > 0) n = std::min<unsigned>(n, (unsigned)c);
+    }
+    auto quota = [](const char *path, const char *period_path) -> double {
+      FILE *f = fopen(path, "r");
+      if (!f) return 0;
+      char a[64] = {0}, b[64] = {0};
+      const int got = fscanf(f, "%63s %63s", a, b);
+      fclose(f);
+      if (got < 1 || !strcmp(a, "max") || atof(a) <= 0) return 0;
+      double period = got >= 2 ? atof(b) : 0;
+      if (period_path) {
+        FILE *g = fopen(period_path, "r");
+        if (g) {
+          if (fscanf(g, "%63s", b) == 1) period = atof(b);
+          fclose(g);
+        }
+      }
+      return period > 0 ? atof(a) / period : 0;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                               // cgroup v2
+    if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");  // v1
+    if (q > 0) n = std::min<unsigned>(n, std::max(1u, (unsigned)(q + 0.5)));
+    if (const char *e = getenv("NIMBLE_CPUS")) n = (unsigned)std::max(1, atoi(e));
+    return std::max(1u, n);
+  }();
+  return cached;
+}
+
 namespace pgzip {
 
 void *huge_map(size_t bytes, void **map, size_t *map_bytes) {

@@ -41,12 +41,10 @@ wantq = run("plain, %d reads" % (N // 4), d + "/q.fastq", N // 4, {})
 assert run("gzip -6 (gzip itself), one thread (zlib)", d + "/q6.fastq.gz", N // 4, {"NIMBLE_GZIP_SERIAL": "1"}, reps=1) == wantq
 assert run("gzip -6 (gzip itself), defaults", d + "/q6.fastq.gz", N // 4, {"NIMBLE_GZIP_DEBUG": "1"}, show=True) == wantq
 p = d + "/r6.fastq.gz"
-for t in (8, 16, 32, 64, 96):
+for t in (16, 32, 64):
     assert run("one member, %d decoder threads" % t, p, N, {"NIMBLE_GZIP_THREADS": str(t)}) == want
 assert run("one member, defaults", p, N, {"NIMBLE_GZIP_DEBUG": "1"}, show=True) == want
-assert run("one member, 64 threads, 64 parser threads", p, N, {"NIMBLE_GZIP_THREADS": "64", "NIMBLE_FASTQ_THREADS": "64"}) == want
 assert run("one member, defaults, 128 MiB windows", p, N, {"NIMBLE_GZIP_WINDOW": str(128 << 20)}) == want
-assert run("one member, defaults, 1 MiB chunks", p, N, {"NIMBLE_GZIP_CHUNK": str(1 << 20)}) == want
-assert run("one member, defaults, table CRC", p, N, {"NIMBLE_NO_CLMUL": "1"}) == want
+assert run("one member, defaults, 8 MiB chunks", p, N, {"NIMBLE_GZIP_CHUNK": str(8 << 20)}) == want
 subprocess.run(["rm", "-rf", d])
 PY
