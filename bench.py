@@ -53,6 +53,25 @@ WORKLOADS = {
 }
 
 
+def usable_cpus():
+    """Host CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 CPUs
+    and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, round(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, round(q / per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def e2e_fastq(names, seqs, reads_np, n_plain, n_gz):
     """The FASTQ pipeline end to end through the argv-compatible CLI (parse + H2D + call + TSV), page cache warm."""
     synth = importlib.import_module("nimble-aligner_amd.synth")
@@ -120,7 +139,7 @@ def main():
                          "the reads are and moves only keys and verdict bytes")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = all host cores, at most 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = the host CPUs this process is granted, at most 64)")
     ap.add_argument("--e2e-reads", type=int, default=8_000_000,
                     help="reads of the end-to-end FASTQ runs at N=1, plain and .gz (0 = skip)")
     args = ap.parse_args()
@@ -390,7 +409,7 @@ def main():
             ref = ora.Reference.from_columns(lib_obj[1]["headers"], cols, "")
             cfg = ora.config_from_json(lib_obj[0], len(names), "unstranded")
             oidx = ora.Index.from_reference(ref)
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            threads = args.cpu_threads or min(usable_cpus(), 64)
             offs = synth.fixed_offsets(S, L)
             t1 = time.perf_counter()
             ores = ora.call(oidx, ref, cfg, sample.reshape(-1), offs, None if not paired else sample2.reshape(-1),
