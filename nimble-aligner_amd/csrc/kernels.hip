@@ -30,8 +30,11 @@ namespace nimble {
 namespace {
 
 constexpr int PACK_BLOCK = 256;
-constexpr int ALIGN_BLOCK = 256;
-constexpr int ALIGN_GRID = 2048;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
+#ifndef NIMBLE_ALIGN_BLOCK
+#define NIMBLE_ALIGN_BLOCK 256
+#endif
+constexpr int ALIGN_BLOCK = NIMBLE_ALIGN_BLOCK;  // reads per tile (64 .. 512: the wave counters below hold 8 waves)
+constexpr int ALIGN_GRID = 2048 * 256 / ALIGN_BLOCK;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
 constexpr int LDS_COLS = 4;
 constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds
 constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
@@ -339,11 +342,14 @@ template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __buil
 #endif
 
 // nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
+// (branch-free: a shift by 64 - s is split into 1 + (63 - s) so that s = 0 needs no special case -- the branch the
+// compiler made of `s ? ... : hi` sat in the innermost loop of the walk; the column has a zero word behind the key)
+__device__ __forceinline__ uint64_t funnel(uint64_t hi, uint64_t lo, uint32_t s) {  // s = 0, 2, .. 62
+  return (hi << s) | ((lo >> 1) >> (63u - s));
+}
 __device__ __forceinline__ uint64_t lds_bits(const uint64_t *rd, uint32_t pos, uint32_t nb) {
-  uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
-  uint64_t hi = rd[w * ALIGN_BLOCK], lo = rd[(w + 1) * ALIGN_BLOCK];
-  uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
-  return x >> (64u - 2u * nb);
+  const uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
+  return funnel(rd[w * ALIGN_BLOCK], rd[(w + 1) * ALIGN_BLOCK], s) >> (64u - 2u * nb);
 }
 __device__ __forceinline__ uint32_t lds_base(const uint64_t *rd, uint32_t pos) {
   return (uint32_t)(rd[(pos >> 5) * ALIGN_BLOCK] >> (62u - 2u * (pos & 31u))) & 3u;
@@ -351,9 +357,7 @@ __device__ __forceinline__ uint32_t lds_base(const uint64_t *rd, uint32_t pos) {
 __device__ __forceinline__ uint64_t g_bits(const uint64_t *__restrict__ u, uint64_t pos, uint32_t nb) {
   uint64_t w = pos >> 5;
   uint32_t s = (uint32_t)(pos & 31u) * 2u;
-  uint64_t hi = u[w], lo = u[w + 1];
-  uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
-  return x >> (64u - 2u * nb);
+  return funnel(u[w], u[w + 1], s) >> (64u - 2u * nb);  // (the unitig buffer ends in spare words)
 }
 // nb bases of a unitig at node-relative position pos: from the record while inside its 64 inline bases
 __device__ __forceinline__ uint64_t node_bits(const NodeRec &r, const uint64_t *__restrict__ unitig, uint32_t pos,
@@ -363,13 +367,13 @@ __device__ __forceinline__ uint64_t node_bits(const NodeRec &r, const uint64_t *
     const uint32_t s = (pos & 31u) * 2u;
     const uint64_t hi = pos < 32u ? w0 : w1;
     const uint64_t lo = pos < 32u ? w1 : 0ULL;
-    const uint64_t x = s ? ((hi << s) | (lo >> (64u - s))) : hi;
-    return x >> (64u - 2u * nb);
+    return funnel(hi, lo, s) >> (64u - 2u * nb);
   }
   return g_bits(unitig, (uint64_t)r.q0.z + pos, nb);
 }
 __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t b) {
-  return b == 0 ? v.x : (b == 1 ? v.y : (b == 2 ? v.z : v.w));
+  const uint32_t lo = (b & 1u) ? v.y : v.x, hi = (b & 1u) ? v.w : v.z;
+  return (b & 2u) ? hi : lo;
 }
 
 // finish a probe whose first slot neither matched nor was empty (linear probing, rare)
@@ -505,8 +509,9 @@ __device__ __forceinline__ uint64_t desc_mask(const uint4 &d) { return u64of(d.z
 __device__ __forceinline__ uint64_t mask_in_window(const uint4 &d, uint32_t base) {
   const uint64_t m = desc_mask(d);
   const int32_t delta = (int32_t)(d.y - base);
-  if (delta >= 0) return delta < 64 ? (m << delta) : 0ULL;
-  return -delta < 64 ? (m >> (-delta)) : 0ULL;
+  const uint32_t ad = (uint32_t)(delta < 0 ? -delta : delta);
+  const uint64_t v = delta < 0 ? (m >> (ad & 63u)) : (m << (ad & 63u));  // selects, no branch: this sits in the walk loop
+  return ad < 64u ? v : 0ULL;
 }
 
 constexpr uint32_t WIDE_ROWS = 256;
@@ -588,34 +593,6 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 
   }
 }
 
-// compare n bases forward: key[rpos + i] vs unitig[upos + i] (upos node-relative).  Returns the bases
-// accepted; a base that takes this node's mismatch count above `allowed` stops the compare, unaccepted.
-__device__ __forceinline__ uint32_t cmp_fwd(const Lane &ln, const NodeRec &nr, const uint64_t *__restrict__ unitig,
-                                            uint32_t rpos, uint32_t upos, uint32_t n, uint32_t allowed,
-                                            uint32_t &mism, bool &premature) {
-  uint32_t matched = 0, seen = 0;
-  premature = false;
-  while (matched < n) {
-    uint32_t c = n - matched < 32u ? n - matched : 32u;
-    uint64_t x = lds_bits(ln.rd, rpos + matched, c) ^ node_bits(nr, unitig, upos + matched, c);
-    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
-    uint32_t cnt = (uint32_t)__popcll(m);
-    if (seen + cnt <= allowed) {
-      seen += cnt;
-      mism += cnt;
-      matched += c;
-    } else {
-      uint32_t k = allowed - seen;  // tolerated here; mismatch k+1 breaks
-      for (uint32_t t = 0; t < k; ++t) m &= ~(1ULL << (63 - __clzll((long long)m)));
-      uint32_t bit = 63u - (uint32_t)__clzll((long long)m);
-      matched += c - 1u - (bit >> 1);
-      mism += k + 1;
-      premature = true;
-      break;
-    }
-  }
-  return matched;
-}
 // compare n bases backward: key[rlast - i] vs unitig[ulast - i]
 __device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const NodeRec &nr, const uint64_t *__restrict__ unitig,
                                             uint32_t rlast, uint32_t ulast, uint32_t n, uint32_t allowed,
@@ -707,33 +684,72 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
       }
       first = false;
     }
-    while (!done && !need_seed) {  // WALK phase: one unitig per iteration
-      NodeRec nr = load_node(ix, node);
-      kmer_pos += KMER;
-      cov += KMER;
-      push_col(ln, nr.q0.y, nr_desc(nr));
-      uint32_t remaining = L - kmer_pos;
-      uint32_t ref_off = koff + KMER;
-      uint32_t informative = nr_len(nr) - ref_off;
-      uint32_t n = remaining < informative ? remaining : informative;
+    // WALK phase, flattened: one iteration = (enter the next unitig, if the lane stands at one) + (compare ONE stretch of at
+    // most 32 bases) + (leave the unitig, if that stretch was its last).  With a loop per unitig around a loop per stretch
+    // the wave ran max-over-lanes stretches for every unitig (5 x 8 iterations for reads that need 8 each); here a lane
+    // takes as many iterations as it has stretches, whatever unitigs they fall in.
+    bool need_node = true;
+    NodeRec nr;
+    uint32_t upos = 0, n_left = 0, seen = 0;
+    while (!done && !need_seed) {
+      if (need_node) {
+        need_node = false;
+        nr = load_node(ix, node);
+        kmer_pos += KMER;
+        cov += KMER;
+        push_col(ln, nr.q0.y, nr_desc(nr));
+        const uint32_t remaining = L - kmer_pos;
+        upos = koff + KMER;
+        const uint32_t informative = nr_len(nr) - upos;
+        n_left = remaining < informative ? remaining : informative;
+        seen = 0;
+      }
       bool prem = false;
-      uint32_t matched = 0;
-      if (n) matched = cmp_fwd(ln, nr, ix.unitig, base0 + kmer_pos, ref_off, n, allowed, mm, prem);
-      cov += matched;
-      kmer_pos += matched;
-      if (kmer_pos >= L) {
-        done = true;
-      } else {
-        uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
-        if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
-          node = sel4(nr.re, nbase);
-          koff = 0;
-          kmer_pos -= KMER - 1;
-          cov -= KMER - 1;
-        } else if (kmer_pos > last_kmer_pos) {
+      if (n_left) {
+        const uint32_t c = n_left < 32u ? n_left : 32u;
+        const uint64_t x = lds_bits(ln.rd, base0 + kmer_pos, c) ^ node_bits(nr, ix.unitig, upos, c);
+        uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t adv = c;
+        if (allowed == 0) {  // (uniform) the usual setting: the first mismatch ends the compare -- selects, no branch
+          prem = cnt != 0;
+          const uint32_t bit = 63u - (uint32_t)__clzll((long long)(m | 1ULL));
+          adv = prem ? c - 1u - (bit >> 1) : c;
+          mm += prem ? 1u : 0u;
+          n_left = prem ? 0u : n_left - c;
+        } else if (seen + cnt <= allowed) {
+          seen += cnt;
+          mm += cnt;
+          n_left -= c;
+        } else {  // the base that takes this unitig's mismatches above `allowed` ends the compare, unaccepted
+          const uint32_t k = allowed - seen;
+          for (uint32_t t = 0; t < k; ++t) m &= ~(1ULL << (63 - __clzll((long long)m)));
+          const uint32_t bit = 63u - (uint32_t)__clzll((long long)m);
+          adv = c - 1u - (bit >> 1);
+          mm += k + 1;
+          prem = true;
+          n_left = 0;
+        }
+        cov += adv;
+        kmer_pos += adv;
+        upos += adv;
+      }
+      if (n_left == 0) {  // the unitig is done: on to its successor, a new seed, or the end
+        if (kmer_pos >= L) {
           done = true;
         } else {
-          need_seed = true;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
+          const uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
+          if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
+            node = sel4(nr.re, nbase);
+            koff = 0;
+            kmer_pos -= KMER - 1;
+            cov -= KMER - 1;
+            need_node = true;
+          } else if (kmer_pos > last_kmer_pos) {
+            done = true;
+          } else {
+            need_seed = true;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
+          }
         }
       }
     }

@@ -276,9 +276,11 @@ def _crc32_combine(crc1, crc2, len2):
     return crc1 ^ crc2
 
 
-def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 << 20):
+def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 << 20, mix=None, subst=0.005):
     """Same recipe as make_reads (single-end) with torch ops, generating straight into device memory.
-    Returns a uint8 tensor [n, L] on `device`.  Deterministic for (n, seed) on a given torch build."""
+    Returns a uint8 tensor [n, L] on `device`.  Deterministic for (n, seed) on a given torch build.
+    `mix` = cumulative shares (on-target, off-target, duplicate, low-complexity; the rest carry N) and `subst` = per-base
+    substitution rate: the defaults are the bench recipe, other values are for probing the kernel (tools/mix_probe.py)."""
     import torch
 
     cat_np, off_np = _codes(seqs)
@@ -294,7 +296,7 @@ def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 <<
     T = len(seqs)
     out = torch.empty((n, L), dtype=torch.uint8, device=dev)
     kind = torch.rand(n, generator=g, device=dev)
-    K_ON, K_OFF, K_DUP, K_LOW = 0.75, 0.90, 0.95, 0.98
+    K_ON, K_OFF, K_DUP, K_LOW = mix if mix is not None else (0.75, 0.90, 0.95, 0.98)
     ar = torch.arange(L, device=dev)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
@@ -307,7 +309,7 @@ def make_reads_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 <<
         strand = torch.rand(m, generator=g, device=dev) < 0.5
         rc = 3 - codes.flip(1)
         codes = torch.where(strand[:, None], rc, codes)
-        mask = torch.rand((m, L), generator=g, device=dev) < 0.005
+        mask = torch.rand((m, L), generator=g, device=dev) < subst
         bump = torch.randint(1, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)
         codes = torch.where(mask, (codes + bump) % 4, codes)
         rnd = torch.randint(0, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)

@@ -1,0 +1,50 @@
+"""Where k_align's time goes (development aid): the align stage on read sets of one kind each.
+python tools/mix_probe.py [T] [N]"""
+import importlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+nim = importlib.import_module("nimble-aligner_amd")
+synth = importlib.import_module("nimble-aligner_amd.synth")
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+names, seqs = synth.make_library(T)
+lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index(0)
+ctx = lib.device_context()
+CASES = [
+    ("bench recipe", None, 0.005),
+    ("on-target, exact", (1.0, 1.0, 1.0, 1.0), 0.0),
+    ("on-target, 0.5 % substitutions", (1.0, 1.0, 1.0, 1.0), 0.005),
+    ("on-target, 2 % substitutions", (1.0, 1.0, 1.0, 1.0), 0.02),
+    ("off-target (random bases)", (0.0, 1.0, 1.0, 1.0), 0.0),
+    ("75 % exact + 25 % off-target", (0.75, 1.0, 1.0, 1.0), 0.0),
+    ("exact, every 64 consecutive reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
+    ("exact, all reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
+    ("exact, every 4 consecutive reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
+]
+if os.environ.get("MIX_CASE"):
+    CASES = [CASES[int(os.environ["MIX_CASE"])]]
+for tag, mix, subst in CASES:
+    reads = synth.make_reads_torch(seqs, N, L=150, seed=synth.READ_SEED, device="cuda:0", mix=mix, subst=subst)
+    if "every 64" in tag:
+        reads = reads[::64].repeat_interleave(64, dim=0)[:N].contiguous()
+    elif "every 4" in tag:
+        reads = reads[::4].repeat_interleave(4, dim=0)[:N].contiguous()
+    elif "all reads identical" in tag:
+        reads = reads[:1].expand(N, -1).contiguous()
+    torch.cuda.synchronize()
+    best = None
+    for rep in range(4):
+        ctx.set_counters(rep == 0)
+        lib.score_call_raw(reads, None, n=N, fixed_len=150, max_len=150, mem=nim.MEM_DEVICE)
+        t = ctx.timing()
+        if rep == 0:
+            c = ctx.counters() if hasattr(ctx, "counters") else {}
+        else:
+            best = t["align"] if best is None else min(best, t["align"])
+    print("%-34s k_align %.3f ms   %s" % (tag, best, {k: c[k] for k in ("probes", "nodes", "seeded") if k in c}), flush=True)
+    del reads
