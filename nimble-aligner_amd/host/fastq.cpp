@@ -135,12 +135,14 @@ bool read_record(Lines &ln, FastqData &out, const char *malformed) {
     ++seq_lines;
     more = ln.next(b, len);
   }
-  size_t qual_len = 0;
+  // rust-bio reads the quality lines raw, terminators included, and calls the record incomplete only when that text is
+  // empty, i.e. when not one quality line could be read; a BLANK quality line is a line ("\n") and the record stands
+  size_t qual_lines = 0;
   for (size_t k = 0; k < seq_lines; ++k) {
     if (!ln.next(b, len)) break;
-    qual_len += trimmed(b, len);
+    ++qual_lines;
   }
-  if (qual_len == 0) throw Panic(std::string(malformed) + ": Unable to read sequence");  // IncompleteRecord
+  if (qual_lines == 0) throw Panic(std::string(malformed) + ": Unable to read sequence");  // IncompleteRecord
   const uint64_t rl = out.bases.size() - out.offsets.back();
   if (rl > out.max_len) out.max_len = (uint32_t)rl;
   out.offsets.push_back(out.bases.size());
@@ -159,6 +161,22 @@ FastqData read_fastq(const std::string &path, bool is_mate) {
   FastqData out;
   out.offsets.push_back(0);
   while (read_record(ln, out, malformed_text(is_mate))) {
+  }
+  return out;
+}
+
+FastqData read_fastq_lazy(const std::string &path, bool is_mate, uint64_t max_records, std::string *error) {
+  LineSource ln(path);
+  FastqData out;
+  out.offsets.push_back(0);
+  error->clear();
+  try {
+    while (out.n() < max_records && read_record(ln, out, malformed_text(is_mate))) {
+    }
+  } catch (const Panic &e) {
+    // (the record that failed may have left bases behind the last offset: cut them)
+    out.bases.resize((size_t)out.offsets.back());
+    *error = e.what();
   }
   return out;
 }
@@ -854,10 +872,21 @@ void whole_file(const std::vector<std::string> &input_files,
                 const std::vector<std::string> &output_paths) {
   // The reference re-opens the file(s) for every library (process/fastq.rs:15-23); parsing once and
   // re-using the in-memory reads is equivalent.
-  parse::fastq::FastqData r1 = parse::fastq::read_fastq(input_files.at(0), false);
+  // The reference pulls one R1 record, then one R2 record, and panics at the first that fails (align.rs:511-541): R2 is
+  // never read beyond R1's last good record, and of two faults the one with the smaller record index fires (R1 first at
+  // equal index).  So: R1 up to its first malformed record, R2 for at most that many records, then the faults in order.
+  std::string err1, err2;
+  parse::fastq::FastqData r1 = parse::fastq::read_fastq_lazy(input_files.at(0), false, ~0ULL, &err1);
   parse::fastq::FastqData r2;
   const bool paired = input_files.size() > 1;
-  if (paired) r2 = parse::fastq::read_fastq(input_files[1], true);
+  if (paired) {
+    r2 = parse::fastq::read_fastq_lazy(input_files[1], true, r1.n(), &err2);
+    if (r2.n() < r1.n()) {
+      if (!err2.empty()) throw Panic(err2);
+      throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+    }
+  }
+  if (!err1.empty()) throw Panic(err1);
   for (size_t i = 0; i < reference_indices.size(); ++i) {
     align::ReadBatch b1;
     b1.bases = r1.bases.data();

@@ -305,6 +305,9 @@ struct FastqData {
 // Panics with "Error -- could not parse read. Input R1 data malformed." (src/align.rs:517) /
 // "... reverse read. Input R2 data malformed." (src/align.rs:541) on a malformed record.
 FastqData read_fastq(const std::string &path, bool is_mate);
+// The same, the way the reference's lazy iterators behave: at most `max_records` records are read, and a malformed record
+// ends the read with its panic text in *error (empty when none) instead of panicking here.
+FastqData read_fastq_lazy(const std::string &path, bool is_mate, uint64_t max_records, std::string *error);
 
 // The same reader, incremental: batches in file order.  Compressed files: one thread inflates and parses ahead,
 // `batch_reads` records per batch.  Plain files: the mapped file is parsed in 8 MiB chunks by a pool of up to 8 threads

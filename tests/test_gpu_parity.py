@@ -8,7 +8,11 @@ import json
 import os
 
 import numpy as np
+import sys
+
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import oracle as ora
 
@@ -170,6 +174,30 @@ def test_unit_index_cases():
             assert names[3] == "SuccessfulMatch" and idx.eq_class(rec["cls"][3]) == [1]
         if thr == 1000:
             assert names[4] == "ScoreBelowThreshold"
+
+
+def test_walk_rules_hand_derived_vectors():
+    # the vectors of tests/hand_vectors.py (walked on paper) on the HIP path: coverage, mismatches and class per read
+    import hand_vectors as hv
+    idx = nim.Index(hv.SEQS)
+    ctx = nim.Context(idx)
+    for nm in (0, 1):
+        cases = [c for c in hv.CASES if c["allowed"] == nm]
+        # thresholds that let every walk through to its class (the filters are not what is under test)
+        p = nim.AlignParams.make(0.0, 0, nm, min_read_length=12)
+        ctx.call_reads(p, [c["read"] for c in cases])
+        rec = ctx.read_records(0)
+        for i, c in enumerate(cases):
+            name = nim.REASONS[int(rec["reason"][i])]
+            if c["coverage"] is None:
+                assert name == "NoMatch", c["name"]  # (long enough for the length filter, too short for a k-mer)
+                continue
+            assert (int(rec["score"][i]), int(rec["mismatches"][i])) == (c["coverage"], c["mismatches"]), (c["name"], c["why"])
+            if c["mismatches"] <= nm:
+                assert name == "SuccessfulMatch", (c["name"], name)
+                assert [hv.NAMES[r] for r in idx.eq_class(int(rec["cls"][i]))] == c["cls"], c["name"]
+            else:
+                assert name == "AboveMismatchThreshold", (c["name"], name)
 
 
 @pytest.fixture(scope="module")

@@ -396,6 +396,68 @@ def test_fastq_pipeline_streams_batches(synth_lib, tmp_path, monkeypatch):
     assert open(out).read() == "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
 
 
+@pytest.mark.parametrize("batch", ["0", "300"])
+def test_fastq_pull_order_and_blank_quality_line(synth_lib, tmp_path, monkeypatch, batch):
+    # The reference pulls R1 record i, then R2 record i (align.rs:511-541), so (a) R2 is never read beyond R1's last
+    # record -- garbage there is not seen, (b) of two faults the smaller record index fires, whichever file it is in,
+    # and (c) a record whose quality line is BLANK parses (rust-bio tests the raw quality text, terminator included, for
+    # emptiness) and its read simply is what the sequence line says.  Whole-file mode ("0") and streamed batches.
+    path, seqs = synth_lib
+    monkeypatch.setenv("NIMBLE_FASTQ_BATCH", batch)
+    monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", "20000")
+    n = 1000
+    r1, r2 = synth.make_reads(seqs, n, paired=True, seed=77)
+    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    exp = oracle_rows(path, "unstranded", r1, r2)
+    want = "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
+    lib = nim.Library(path, "unstranded").build_index()
+    # (a) a malformed record in R2 behind R1's last record
+    f2_tail = str(tmp_path / "r2_tail.fastq")
+    open(f2_tail, "w").write(open(f2).read() + "this is no record\nACGT\n+\nIIII\n")
+    out = str(tmp_path / "a.tsv")
+    nim.fastq_process([f1, f2_tail], [lib], [out])
+    assert open(out).read() == want
+
+    # (b) R1 malformed at record 600, R2 ends after 400 records: the missing mate is pulled first
+    def corrupt(src, dst, rec):
+        lines = open(src).read().split("\n")
+        lines[4 * rec] = "broken header"
+        open(dst, "w").write("\n".join(lines))
+
+    b1 = str(tmp_path / "b1.fastq")
+    corrupt(f1, b1, 600)
+    f2_short = str(tmp_path / "r2_short.fastq")
+    synth.write_fastq(f2_short, r2[:400])
+    with pytest.raises(nim.Panic, match="do not have matching lengths"):
+        nim.fastq_process([b1, f2_short], [lib], [str(tmp_path / "x.tsv")])
+    # ... and the other way round: R2 complete, R1 malformed at 600
+    with pytest.raises(nim.Panic, match="Input R1 data malformed"):
+        nim.fastq_process([b1, f2], [lib], [str(tmp_path / "x.tsv")])
+    # R1 malformed at 600, R2 malformed at 200
+    b2 = str(tmp_path / "b2.fastq")
+    corrupt(f2, b2, 200)
+    with pytest.raises(nim.Panic, match="Input R2 data malformed"):
+        nim.fastq_process([b1, b2], [lib], [str(tmp_path / "x.tsv")])
+    # (c) blank quality lines, single-end: same table as with qualities
+    single = synth.make_reads(seqs, 500, seed=78)
+    fq, fb = str(tmp_path / "s.fastq"), str(tmp_path / "s_blank.fastq")
+    synth.write_fastq(fq, single)
+    with open(fb, "w") as f:
+        for i, r in enumerate(single):
+            f.write("@b%d\n%s\n+\n%s\n" % (i, bytes(r).decode(), "" if i % 3 == 0 else "I" * len(r)))
+    oq, ob = str(tmp_path / "q.tsv"), str(tmp_path / "b.tsv")
+    nim.fastq_process([fq], [lib], [oq])
+    nim.fastq_process([fb], [lib], [ob])
+    assert open(ob).read() == open(oq).read()
+    # ... but a record that ends before any quality line is incomplete
+    ft = str(tmp_path / "s_trunc.fastq")
+    open(ft, "w").write(open(fq).read() + "@last\nACGTACGT\n+\n")
+    with pytest.raises(nim.Panic, match="Input R1 data malformed"):
+        nim.fastq_process([ft], [lib], [str(tmp_path / "x.tsv")])
+
+
 @pytest.mark.parametrize("paired", [False, True])
 def test_device_routing_of_exchange_records(synth_lib, paired):
     # nimble_route_records / nimble_unpack_records: every read lands in the bucket of hash % world, buckets are

@@ -292,6 +292,18 @@ def test_read_fastq_fixtures_and_gzip(tmp_path):
     multi = tmp_path / "multi.fastq"
     multi.write_text("@a desc\nACGT\nAC\n+\nIIII\nII\n@b\nGG\n+\nII")
     assert nim.read_fastq_stats(str(multi)) == (2, 8, 6)
+    # rust-bio calls a record incomplete when its raw quality text (terminators included) is empty: a BLANK quality
+    # line is text, the record stands; a record that ends before any quality line is incomplete
+    blank = tmp_path / "blank.fastq"
+    blank.write_text("@a\nACGT\n+\n\n@b\nGG\n+\nII\n")
+    assert nim.read_fastq_stats(str(blank)) == (2, 6, 4)
+    assert nim.read_fastq_batched_stats(str(blank), 16)[:3] == (2, 6, 4)
+    cut = tmp_path / "cut.fastq"
+    cut.write_text("@a\nACGT\n+\nIIII\n@b\nGG\n+\n")
+    with pytest.raises(nim.Panic, match="Unable to read sequence"):
+        nim.read_fastq_stats(str(cut))
+    with pytest.raises(nim.Panic, match="Unable to read sequence"):
+        nim.read_fastq_batched_stats(str(cut), 16)
 
 
 def _fnv_records(records):

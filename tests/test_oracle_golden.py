@@ -6,7 +6,11 @@ src/filter/align.rs, src/utils.rs and src/reference_library.rs of the reference.
 import json
 import os
 
+import sys
+
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import oracle as ora
 
@@ -98,6 +102,22 @@ def test_per_read_hand_derived_values():
                 cls, cov, mm = got
                 assert [rows[i] for i in cls] == exp[0], (lib, name, nm)
                 assert (cov, mm) == (exp[1], exp[2]), (lib, name, nm)
+
+
+def test_walk_rules_hand_derived_vectors():
+    # seed stride 3, the 0.2 * len left-extension rule, a fork, a dead end, a re-seed: expected values walked on paper
+    # (tests/hand_vectors.py), not produced by any implementation
+    import hand_vectors as hv
+    index = ora.Index.from_sequences(hv.SEQS)
+    assert sorted(len(index.node(n)[0]) for n in range(index.stats()["nodes"])) == [59, 59, 80, 100]
+    for c in hv.CASES:
+        got = index.map_read(c["read"], c["allowed"])
+        if c["coverage"] is None:
+            assert got is None, c["name"]
+            continue
+        cls, cov, mm = got
+        assert [hv.NAMES[i] for i in cls] == c["cls"], c["name"]
+        assert (cov, mm) == (c["coverage"], c["mismatches"]), (c["name"], c["why"])
 
 
 def test_basic_graph_shape():
