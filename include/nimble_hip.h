@@ -128,8 +128,9 @@ int nimble_ctx_set_option(nimble_ctx *, int option, int64_t value);
 
 /* Memory space of the read buffers handed to nimble_call */
 /* NIMBLE_MEM_HOST_PINNED (nimble_stream_append only): page-locked host buffers (nimble_pinned_alloc / _register) that the
- * caller leaves untouched until the NEXT nimble_stream_append or nimble_stream_end on the context has returned -- the copy of
- * batch i then runs while the host prepares batch i + 1 instead of being waited for. */
+ * caller leaves untouched until the SECOND following nimble_stream_append, or nimble_stream_end, on the context has returned
+ * -- the copy of batch i then runs while the host prepares batch i + 1 and queues its copy behind it, so the link does
+ * not idle between batches (three batches' buffers are in use at a time). */
 enum { NIMBLE_MEM_HOST = 0, NIMBLE_MEM_DEVICE = 1, NIMBLE_MEM_HOST_PINNED = 2 };
 
 /* ---- the hot path: replaces score::call (src/score.rs:14-46) up to, and excluding, the

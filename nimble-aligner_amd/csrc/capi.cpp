@@ -130,7 +130,7 @@ struct nimble_ctx {
   hipEvent_t ev_h2d[2] = {}, ev_used[2] = {};
   bool stage_busy[2] = {false, false};
   int stage_k = 0;
-  int h2d_pending = -1;  // staging slot whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
+  bool h2d_pending[2] = {false, false};  // staging slots whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
@@ -1481,7 +1481,7 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   c->stream_max_len = max_len;
   c->stage_busy[0] = c->stage_busy[1] = false;
   c->stage_k = 0;
-  c->h2d_pending = -1;
+  c->h2d_pending[0] = c->h2d_pending[1] = false;
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->defer.active = false;
   c->defer.world = 0;
@@ -1515,10 +1515,14 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   const uint64_t *in_off[2] = {r1_off, r2_off};
   const int k = c->stage_k;
   const bool lazy = mem == NIMBLE_MEM_HOST_PINNED;
-  if (c->h2d_pending >= 0) {  // the batch before this one has left its page-locked buffers by now (or is waited for)
-    HIPCHK(hipEventSynchronize(c->ev_h2d[c->h2d_pending]));
-    c->h2d_pending = -1;
-  }
+  // Page-locked batches: the copy of the batch before this one may still run -- the link never idles while the host
+  // queues the next batch's work -- and the one before that (the last user of staging slot k and of its event) is waited
+  // for here.  A batch in any other memory ends every copy still pending first.
+  for (int q = 0; q < 2; ++q)
+    if (c->h2d_pending[q] && (q == k || !lazy)) {
+      HIPCHK(hipEventSynchronize(c->ev_h2d[q]));
+      c->h2d_pending[q] = false;
+    }
   if (lazy) mem = NIMBLE_MEM_HOST;
   if (mem == NIMBLE_MEM_HOST) {
     // device staging slot k: wait until the pack kernel that read it last has run, copy on the side stream
@@ -1581,7 +1585,7 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
   HIPCHK(hipGetLastError());
   if (mem == NIMBLE_MEM_HOST) {
-    if (lazy) c->h2d_pending = k;                      // waited for by the next append / the end of the stream
+    if (lazy) c->h2d_pending[k] = true;                // waited for by the next append but one / the end of the stream
     else HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
   }
   c->stream_n += m;
@@ -1592,10 +1596,11 @@ int nimble_stream_end(nimble_ctx *c) {
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_end: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_end: no streamed call is open");
   HIPCHK(hipSetDevice(c->ix->device));
-  if (c->h2d_pending >= 0) {
-    HIPCHK(hipEventSynchronize(c->ev_h2d[c->h2d_pending]));
-    c->h2d_pending = -1;
-  }
+  for (int q = 0; q < 2; ++q)
+    if (c->h2d_pending[q]) {
+      HIPCHK(hipEventSynchronize(c->ev_h2d[q]));
+      c->h2d_pending[q] = false;
+    }
   c->streaming = false;
   c->cb.n = c->stream_n;
   c->cb.key_stride = c->stream_cap;

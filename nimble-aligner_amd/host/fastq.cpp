@@ -780,16 +780,17 @@ uint64_t file_size(const std::string &p) {
 struct Cursor {
   parse::fastq::BatchReader rd;
   std::unique_ptr<parse::fastq::BatchReader::Batch> b;
-  // the batch before the current one: its copy to the device may still run (NIMBLE_MEM_HOST_PINNED: buffers stay untouched
-  // until the NEXT append has returned), so it goes back to the reader one step late
-  std::unique_ptr<parse::fastq::BatchReader::Batch> held;
+  // the two batches before the current one: their copies to the device may still run (NIMBLE_MEM_HOST_PINNED: buffers stay
+  // untouched until the second following append has returned), so a batch goes back to the reader two steps late
+  std::unique_ptr<parse::fastq::BatchReader::Batch> held, held2;
   uint64_t used = 0;
   Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads) {}
   uint64_t avail() const { return b ? b->data.n() - used : 0; }
   bool at_end() const { return b && b->last && used == b->data.n(); }  // the file's event (EOF or bad record) is next
   void fill() {  // make records available unless the file is at its event
     while (!b || (used == b->data.n() && !b->last)) {
-      if (held) rd.recycle(std::move(held));
+      if (held2) rd.recycle(std::move(held2));
+      held2 = std::move(held);
       held = std::move(b);
       b = rd.next();
       used = 0;
@@ -812,11 +813,26 @@ void streamed(const std::vector<std::string> &input_files,
   std::vector<std::unique_ptr<align::CallStream>> streams;
   uint32_t stream_max_len = 0;
   const std::string lengths = "Error -- read and reverse read files do not have matching lengths: ";
+  // where the consumer's time goes (NIMBLE_HOST_TIMING): waiting for parsed batches, opening the streams, appending
+  double t_fill = 0, t_open = 0, t_append = 0, t_finish = 0;
+  uint64_t n_appends = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
   for (;;) {
+    const auto tf = now();
     c1.fill();
     if (paired) c2->fill();
+    t_fill += secs(tf, now());
     const uint64_t n = paired ? std::min(c1.avail(), c2->avail()) : c1.avail();
     if (streams.empty()) {
+      const auto to = now();
+      struct Lap {
+        double &acc;
+        std::chrono::steady_clock::time_point t0;
+        ~Lap() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+      } lap{t_open, to};
       const uint32_t ml = std::max<uint32_t>(c1.b->data.max_len, paired ? c2->b->data.max_len : 0u);
       stream_max_len = std::max<uint32_t>(32, (ml + 31u) / 32u * 32u);
       uint64_t cap = n;  // capacity from the bytes the first batch took on disk
@@ -843,7 +859,10 @@ void streamed(const std::vector<std::string> &input_files,
         m.max_len = c2->b->data.max_len;
         m.pinned = c2->b->pinned[0] != nullptr;
       }
+      const auto ta = now();
       for (auto &st : streams) st->append(a, paired ? &m : nullptr);
+      t_append += secs(ta, now());
+      ++n_appends;
       c1.used += n;
       if (paired) c2->used += n;
       continue;  // look again: one of the files may simply need its next batch
@@ -856,6 +875,7 @@ void streamed(const std::vector<std::string> &input_files,
     // R1 still has a record, so R2 is at its event: a missing mate or a malformed one
     throw Panic(c2->b->error.empty() ? lengths : c2->b->error);
   }
+  const auto tfin = now();
   for (size_t i = 0; i < streams.size(); ++i) {
     align::CallOutput res = streams[i]->finish(references.at(i));
     res.materialize();
@@ -863,6 +883,10 @@ void streamed(const std::vector<std::string> &input_files,
               [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
     utils::write_to_tsv(res.rows, output_paths.at(i));
   }
+  t_finish = secs(tfin, now());
+  if (getenv("NIMBLE_HOST_TIMING"))
+    fprintf(stderr, "[nimble host] consumer: %.3f s waiting for parsed batches, %.3f s opening the call, %.3f s in %llu appends, "
+            "%.3f s finishing (tail of the call, coercion, TSV)\n", t_fill, t_open, t_append, (unsigned long long)n_appends, t_finish);
 }
 
 void whole_file(const std::vector<std::string> &input_files,
