@@ -252,6 +252,16 @@ int nimble_stream_begin(nimble_ctx *, const nimble_align_params *, int paired, u
                         uint64_t capacity_hint);
 int nimble_stream_append(nimble_ctx *, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                          const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
+/* The same batch handed over already packed, for a host whose link to the device is the bottleneck (a 150-base read is
+ * 40 + 4 bytes this way instead of 150 + 8): mate m of read i is r<m>_len[i] bases in the r<m>_stride 64-bit words at
+ * r<m>_words + i * r<m>_stride, 32 bases a word, the first base in the highest bit pair, A=0 C=1 G=2 T=3 (either case),
+ * any other byte packed as A -- what DnaString::from_acgt_bytes makes of it (src/align.rs:576-579 builds the read key from
+ * those) -- and zero bits behind the last base.  Results are those of nimble_stream_append on the same reads.  The
+ * buffers are page-locked host memory (nimble_pinned_alloc / _register) and stay untouched until the SECOND following
+ * append, or nimble_stream_end, has returned (as NIMBLE_MEM_HOST_PINNED).  Batches of both forms may be mixed in one
+ * stream. */
+int nimble_stream_append_packed(nimble_ctx *, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
+                                const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t m);
 int nimble_stream_end(nimble_ctx *);
 /* page-locked host memory for the batches (full-rate asynchronous H2D) */
 int nimble_pinned_alloc(uint64_t bytes, void **out);

@@ -153,6 +153,10 @@ int nimble_host_bam_dump(const char *input, int force_bam_paired, const char *ou
 /* The parallel gzip decoder of the FASTQ reader on its own (diagnostic): the decompressed stream written to out_path. */
 int nimble_host_pgzip_decompress(const char *path, int threads, const char *out_path, uint64_t *n_pieces);
 /* process/bam.rs:407-423 */
+/* The FASTQ reader's packer, for tests and for callers that build batches themselves: n reads (ASCII, off[n + 1]) into the
+ * form nimble_stream_append_packed takes (include/nimble_hip.h): read i in words[i * stride ..], lens[i] its length. */
+int nimble_host_pack_reads_2bit(const uint8_t *bases, const uint64_t *off, uint64_t n, uint32_t stride, uint64_t *words,
+                                uint32_t *lens);
 int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap);
 int nimble_host_parse_str_as_bool(const char *v, int *out);
 int nimble_write_to_tsv(const nimble_rows *, const char *output_path);
@@ -173,6 +177,11 @@ int nimble_host_read_fastq(const char *path, uint64_t *n, uint64_t *bases, uint3
  * records before it and the return is -1 with the reference's panic text */
 int nimble_host_read_fastq_batched(const char *path, uint64_t batch_reads, uint64_t *n, uint64_t *bases,
                                    uint32_t *max_len, uint64_t *n_batches, uint64_t *checksum);
+/* the same reader in the mode the pipeline runs it in (batches packed for nimble_stream_append_packed, no ASCII copy where
+ * the file allows it): the same totals, and the checksum over (length, bases) with the bases as the packed words spell them
+ * (upper case, anything that is no A/C/G/T as A); also checks that nothing but zero bits follows a read's last base */
+int nimble_host_read_fastq_packed(const char *path, uint64_t batch_reads, uint64_t *n, uint64_t *bases, uint32_t *max_len,
+                                  uint64_t *n_batches, uint64_t *checksum);
 const char *nimble_host_filter_reason_text(int reason); /* Display for FilterReason */
 
 #ifdef __cplusplus

@@ -87,7 +87,7 @@ HIP_SYMBOLS = [
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
-    "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_end",
+    "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_append_packed", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
@@ -132,6 +132,7 @@ def hip_lib():
         L.nimble_call_packed.argtypes = [vp, C.POINTER(AlignParams), C.POINTER(NimblePacked), u64, u32]
         L.nimble_stream_begin.argtypes = [vp, C.POINTER(AlignParams), i32, u32, u64]
         L.nimble_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
+        L.nimble_stream_append_packed.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64]
         L.nimble_stream_end.argtypes = [vp]
         L.nimble_pinned_alloc.argtypes = [u64, C.POINTER(vp)]
         L.nimble_pinned_free.argtypes = [vp]
@@ -356,8 +357,17 @@ class Context:
                                               mem))
         self.n += n
 
+    def stream_append_packed(self, w1, len1, stride1, w2=None, len2=None, stride2=0):
+        """nimble_stream_append_packed: a batch the host has packed (pack_reads_2bit).  The arrays are kept alive here until
+        the stream ends (the copy runs behind the call)."""
+        n = int(len(len1))
+        self._keep_packed = getattr(self, "_keep_packed", []) + [(w1, len1, w2, len2)]
+        _check(hip_lib().nimble_stream_append_packed(self.h, _ptr(w1), _ptr(len1), stride1, _ptr(w2), _ptr(len2), stride2, n))
+        self.n += n
+
     def stream_end(self):
         _check(hip_lib().nimble_stream_end(self.h))
+        self._keep_packed = []
 
     def call_reads(self, params, reads, mates=None):
         b1, o1 = pack_reads(reads)
@@ -468,9 +478,9 @@ HOST_SYMBOLS = [
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
-    "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_score_call_umis", "nimble_umi_rows_free",
+    "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_host_read_fastq_packed", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
-    "nimble_fastq_process_sharded", "nimble_bam_process", "nimble_host_bam_dump", "nimble_host_reverse_comp_if_needed",
+    "nimble_fastq_process_sharded", "nimble_bam_process", "nimble_host_bam_dump", "nimble_host_pack_reads_2bit", "nimble_host_reverse_comp_if_needed",
     "nimble_host_parse_str_as_bool", "nimble_host_pgzip_decompress",
 ]
 
@@ -545,6 +555,8 @@ def host_lib():
         L.nimble_umi_rows_filter.argtypes = [vp, u64, C.POINTER(i32 * 5)]
         L.nimble_host_read_fastq_batched.argtypes = [cp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32),
                                                      C.POINTER(u64), C.POINTER(u64)]
+        L.nimble_host_read_fastq_packed.argtypes = [cp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32),
+                                                     C.POINTER(u64), C.POINTER(u64)]
         L.nimble_score_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
         L.nimble_score_stream_end.argtypes = [vp, C.POINTER(vp)]
         L.nimble_library_ctx_slot.restype = vp
@@ -561,6 +573,7 @@ def host_lib():
         L.nimble_bam_process.argtypes = [cp, i32, C.POINTER(vp), pp, i32, i32]
         L.nimble_host_bam_dump.argtypes = [cp, i32, cp]
         L.nimble_host_reverse_comp_if_needed.argtypes = [cp, i32, cp, u64]
+        L.nimble_host_pack_reads_2bit.argtypes = [vp, vp, u64, u32, vp, vp]
         L.nimble_host_parse_str_as_bool.argtypes = [cp, C.POINTER(i32)]
         L.nimble_host_pgzip_decompress.argtypes = [cp, i32, cp, C.POINTER(u64)]
         L.nimble_write_to_tsv.argtypes = [vp, cp]
@@ -1062,12 +1075,34 @@ def read_fastq_stats(path):
     return n.value, b.value, m.value
 
 
+def pack_reads_2bit(reads, stride=None):
+    """The host's packer (parse::fastq::pack_reads_2bit) on a list of reads: (words uint64 [n * stride], lens uint32 [n],
+    stride).  32 bases a word, first base in the highest bit pair, A=0 C=1 G=2 T=3, anything else as A."""
+    flat, off = pack_reads(reads)
+    n = len(off) - 1
+    longest = int((off[1:] - off[:-1]).max()) if n else 0
+    stride = stride or max(1, (longest + 31) // 32)
+    words = np.zeros(n * stride, dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint32)
+    _hcheck(host_lib().nimble_host_pack_reads_2bit(_ptr(flat), _ptr(off), n, stride, _ptr(words), _ptr(lens)))
+    return words, lens, stride
+
+
 def read_fastq_batched_stats(path, batch_reads, checksum=True):
     """The pipeline's threaded batch reader run to the end: (records, bases, max_len, batches, checksum).  The checksum
     is a serial pass over every base; `checksum=False` leaves it out (0) when the reader itself is being timed."""
     n, b, m, nb, h = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
     _hcheck(host_lib().nimble_host_read_fastq_batched(os.fsencode(path), batch_reads, C.byref(n), C.byref(b),
                                                       C.byref(m), C.byref(nb), C.byref(h) if checksum else None))
+    return n.value, b.value, m.value, nb.value, h.value
+
+
+def read_fastq_packed_stats(path, batch_reads):
+    """The batch reader in the pipeline's packed mode run to the end: (records, bases, max_len, batches, checksum); the
+    checksum spells the bases from the packed words (upper case, foreign bytes as A)."""
+    n, b, m, nb, h = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+    _hcheck(host_lib().nimble_host_read_fastq_packed(os.fsencode(path), batch_reads, C.byref(n), C.byref(b), C.byref(m),
+                                                     C.byref(nb), C.byref(h)))
     return n.value, b.value, m.value, nb.value, h.value
 
 

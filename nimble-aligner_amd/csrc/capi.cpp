@@ -1592,6 +1592,87 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
   return NIMBLE_OK;
 }
 
+int nimble_stream_append_packed(nimble_ctx *c, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
+                                const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t m) {
+  if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: NULL context");
+  if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: no streamed call is open");
+  const bool paired = c->cb.paired != 0;
+  if ((r2_words != nullptr) != paired || (r2_len != nullptr) != paired)
+    return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: mates given for a single-end stream or missing for a paired one");
+  if (m == 0) return NIMBLE_OK;
+  if (!r1_words || !r1_len || r1_stride == 0 || (paired && r2_stride == 0))
+    return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: NULL buffer or zero stride");
+  const uint32_t max_len = c->stream_max_len;
+  for (int mt = 0; mt < (paired ? 2 : 1); ++mt) {
+    const uint32_t *len = mt ? r2_len : r1_len;
+    const uint64_t cap = std::min<uint64_t>(max_len, 32ULL * (mt ? r2_stride : r1_stride));
+    for (uint64_t i = 0; i < m; ++i)
+      if (len[i] > cap)
+        return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: a read longer than the stream's max_len or than its words");
+  }
+  if (c->stream_n + m >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: more than 2^32 reads");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc;
+  if (c->stream_n + m > c->stream_cap) {
+    rc = stream_grow(c, std::min<uint64_t>(std::max<uint64_t>(2 * c->stream_cap, c->stream_n + m), 0xFFFFFFEFULL));
+    if (rc) return rc;
+  }
+  const int k = c->stage_k;
+  // as NIMBLE_MEM_HOST_PINNED: the copy of the batch before this one may still run; the one before that is waited for
+  if (c->h2d_pending[k]) {
+    HIPCHK(hipEventSynchronize(c->ev_h2d[k]));
+    c->h2d_pending[k] = false;
+  }
+  if (c->stage_busy[k]) HIPCHK(hipEventSynchronize(c->ev_used[k]));
+  const uint64_t *d_words[2] = {nullptr, nullptr};
+  const uint32_t *d_len[2] = {nullptr, nullptr};
+  for (int mt = 0; mt < (paired ? 2 : 1); ++mt) {
+    const uint64_t wbytes = m * (uint64_t)(mt ? r2_stride : r1_stride) * 8;
+    rc = c->b_stage[k][mt].ensure(std::max<uint64_t>(wbytes, 16), &c->bytes);
+    if (rc) return rc;
+    rc = c->b_stage_off[k][mt].ensure(std::max<uint64_t>(m * 4, 16), &c->bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->b_stage[k][mt].p, mt ? r2_words : r1_words, wbytes, hipMemcpyHostToDevice, c->h2d_stream));
+    HIPCHK(hipMemcpyAsync(c->b_stage_off[k][mt].p, mt ? r2_len : r1_len, m * 4, hipMemcpyHostToDevice, c->h2d_stream));
+    d_words[mt] = c->b_stage[k][mt].as<uint64_t>();
+    d_len[mt] = c->b_stage_off[k][mt].as<uint32_t>();
+  }
+  HIPCHK(hipEventRecord(c->ev_h2d[k], c->h2d_stream));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[k], 0));
+  CallBuffers v = c->cb;
+  const uint64_t B = c->stream_n;
+  v.n = m;
+  v.key_stride = c->stream_cap;
+  v.keys += B;
+  v.key_hash += B;
+  v.slot += B;
+  v.counted += B;
+  for (int mt = 0; mt < 2; ++mt) {
+    v.len[mt] += B;
+    v.alen[mt] += B;
+    v.pre[mt] += B;
+    v.reason[mt] += B;
+    v.score[mt] += B;
+    v.mism[mt] += B;
+    v.cls[mt] += B;
+    v.dyn_off[mt] += B;
+    v.dyn_len[mt] += B;
+    v.dyn_hash[mt] += B;
+    v.dyn_pos[mt] += B;
+  }
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
+  launch_pack_words(c->stream, d_words[0], d_len[0], r1_stride, d_words[1], d_len[1], r2_stride, max_len,
+                    c->prm.min_read_length, c->b_plog.as<double>(), v);
+  HIPCHK(hipEventRecord(c->ev_used[k], c->stream));
+  c->stage_busy[k] = true;
+  c->stage_k ^= 1;
+  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
+  HIPCHK(hipGetLastError());
+  c->h2d_pending[k] = true;
+  c->stream_n += m;
+  return NIMBLE_OK;
+}
+
 int nimble_stream_end(nimble_ctx *c) {
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_end: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_end: no streamed call is open");

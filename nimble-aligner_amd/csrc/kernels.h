@@ -96,6 +96,10 @@ enum { ERR_SCRATCH = 1, ERR_CLASS_CAP = 2, ERR_IDS_CAP = 4, ERR_HIST = 8 };
 void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const uint8_t *r2, const uint64_t *off2,
                  uint32_t fixed_len, uint32_t max_len, uint32_t min_len, const double *plog, uint32_t plog_max_len,
                  const CallBuffers &cb);
+// the same from reads packed by the host: 32 bases a word, `stride` words a read (kernels.hip: k_pack_words)
+void launch_pack_words(hipStream_t s, const uint64_t *w1, const uint32_t *len1, uint32_t stride1, const uint64_t *w2,
+                       const uint32_t *len2, uint32_t stride2, uint32_t max_len, uint32_t min_len, const double *plog,
+                       const CallBuffers &cb);
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
                   int want_counters, int grid_pct = 100);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);

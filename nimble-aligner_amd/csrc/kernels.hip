@@ -259,6 +259,92 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_pack_words: the same outputs as k_pack from reads the host has already packed (nimble_stream_append_packed): mate m of
+// read r is `len[m][r]` bases in words w[m] + r * stride[m], 32 bases a word, first base in the highest bit pair, zero
+// behind the last base (a byte that is no A/C/G/T was packed as A, as k_pack does).  The key is mate 0's bases followed
+// at once by mate 1's; key words, key hash, lengths and prefilter verdicts come out exactly as k_pack writes them.
+// A thread a read: 40 bytes in for a 150-base read, the reads of a wave are neighbours in memory.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_words(const uint64_t *__restrict__ w1, const uint32_t *__restrict__ len1,
+                                                    uint32_t stride1, const uint64_t *__restrict__ w2,
+                                                    const uint32_t *__restrict__ len2, uint32_t stride2, uint32_t max_len,
+                                                    uint32_t min_len, const double *__restrict__ plog, CallBuffers cb) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= cb.n) return;
+  const int nm = cb.paired ? 2 : 1;
+  uint32_t L[2] = {0, 0};
+  for (int m = 0; m < nm; ++m) {
+    uint32_t l = (m ? len2 : len1)[r];
+    if (l > max_len || l > 32u * (m ? stride2 : stride1)) {  // lengths handed over in device memory: cut, and say so
+      atomicOr((unsigned long long *)&cb.state[14], 1ULL);
+      l = 0;
+    }
+    L[m] = l;
+  }
+  const uint32_t total = L[0] + L[1];
+  uint64_t acc = 0, h = 0x8F1BBCDCCA62C1D6ULL ^ (uint64_t)total;
+  uint32_t nb = 0, w = 0;  // bases pending in acc (right-aligned, < 32), key words written
+  auto emit = [&](uint64_t word) {
+    cb.keys[(uint64_t)w * cb.key_stride + r] = word;
+    h = (h ^ word) * 0xff51afd7ed558ccdULL;
+    h ^= h >> 32;
+    ++w;
+  };
+  for (int m = 0; m < nm; ++m) {
+    const uint64_t *src = (m ? w2 : w1) + r * (uint64_t)(m ? stride2 : stride1);
+    const uint32_t len = L[m];
+    uint32_t cT = 0, cG = 0, cC = 0;
+    for (uint32_t done = 0; done < len; done += 32u) {
+      const uint32_t k = len - done < 32u ? len - done : 32u;  // bases in this word
+      uint64_t word = src[done >> 5];
+      if (k < 32u) word &= ~0ULL << (64u - 2u * k);             // (whatever the host left behind the last base)
+      const uint64_t hi = (word >> 1) & 0x5555555555555555ULL, lo = word & 0x5555555555555555ULL;
+      cT += (uint32_t)__popcll(hi & lo);
+      cG += (uint32_t)__popcll(hi & ~lo);
+      cC += (uint32_t)__popcll(~hi & lo);                       // (padding is 00: no C there)
+      // append k bases (left-aligned in `word`) behind the nb pending ones
+      if (nb == 0) {
+        if (k == 32u) emit(word);
+        else { acc = word >> (64u - 2u * k); nb = k; }
+      } else if (nb + k < 32u) {
+        acc = (acc << (2u * k)) | (word >> (64u - 2u * k));
+        nb += k;
+      } else {
+        const uint32_t first = 32u - nb, rest = k - first;      // first >= 1 bases complete the pending word
+        emit((acc << (2u * first)) | (word >> (64u - 2u * first)));
+        acc = rest ? (word << (2u * first)) >> (64u - 2u * rest) : 0ULL;
+        nb = rest;
+      }
+    }
+    cb.len[m][r] = len;
+    const uint32_t cA = len - cT - cG - cC;
+    uint8_t verdict = (uint8_t)R_TODO;
+    if (cb.skip[m] && cb.skip[m][r]) {
+      verdict = NIMBLE_R_SKIPPED_ALIGN_DUE_TO_UNPAIRED_DUMMY;
+    } else if (len < min_len) {
+      verdict = NIMBLE_R_SHORT_READ;
+    } else {
+      const double *row = plog + ((uint64_t)len * (len + 1)) / 2;  // shannon_entropy, terms in the order A, T, C, G
+      double e = 0.0;
+      if (cA) e += row[cA];
+      if (cT) e += row[cT];
+      if (cC) e += row[cC];
+      if (cG) e += row[cG];
+      if (-e < MIN_ENTROPY_SCORE) verdict = NIMBLE_R_HIGH_ENTROPY;
+    }
+    cb.pre[m][r] = verdict;
+  }
+  if (nb) {
+    const uint64_t word = acc << (64u - 2u * nb);
+    cb.keys[(uint64_t)w * cb.key_stride + r] = word;
+    h = (h ^ word) * 0xff51afd7ed558ccdULL;
+    h ^= h >> 32;
+  }
+  for (uint32_t z = w + (nb ? 1u : 0u); z < cb.key_words; ++z) cb.keys[(uint64_t)z * cb.key_stride + r] = 0ULL;
+  cb.key_hash[r] = mix64(h);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_align helpers
 // ---------------------------------------------------------------------------------------------
 
@@ -1848,6 +1934,14 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
   uint32_t grid = blocks_for(cb.n, rpb);
   hipLaunchKernelGGL(k_pack, dim3(grid), dim3(PACK_BLOCK), nm * tile_bytes, s, r1, off1, r2, off2, fixed_len, max_len,
                      rpb, tile_bytes, min_len, plog, cb);
+}
+
+void launch_pack_words(hipStream_t s, const uint64_t *w1, const uint32_t *len1, uint32_t stride1, const uint64_t *w2,
+                       const uint32_t *len2, uint32_t stride2, uint32_t max_len, uint32_t min_len, const double *plog,
+                       const CallBuffers &cb) {
+  if (cb.n == 0) return;
+  hipLaunchKernelGGL(k_pack_words, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, w1, len1, stride1, w2, len2, stride2, max_len,
+                     min_len, plog, cb);
 }
 
 static int resident_blocks(const void *fn, size_t lds) {

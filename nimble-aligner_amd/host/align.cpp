@@ -522,6 +522,13 @@ CallStream::~CallStream() {
 void CallStream::append(const ReadBatch &seqs, const ReadBatch *mates) {
   if ((mates != nullptr) != paired_ || (mates && mates->n != seqs.n))
     throw Panic("Error -- read and reverse read files do not have matching lengths: ");
+  if (seqs.stride && (!mates || mates->stride)) {  // packed by the host's parser threads: a quarter of the bytes on the link
+    check_rc(nimble_stream_append_packed(index_.ctx(), seqs.words, seqs.lens, seqs.stride, mates ? mates->words : nullptr,
+                                         mates ? mates->lens : nullptr, mates ? mates->stride : 0u, seqs.n),
+             "nimble_stream_append_packed");
+    n_ += seqs.n;
+    return;
+  }
   check_rc(nimble_stream_append(index_.ctx(), seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                                 mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len,
                                 seqs.device ? NIMBLE_MEM_DEVICE

@@ -10,6 +10,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -181,19 +182,189 @@ FastqData read_fastq_lazy(const std::string &path, bool is_mate, uint64_t max_re
   return out;
 }
 
+// ---- 2-bit packing on the host: a 150-base read crosses the link as 44 bytes instead of 158 ---------------------------
+namespace {
+// 32 ASCII bases -> one word, first base in the highest bit pair
+__attribute__((target("avx2"))) inline uint64_t pack32_avx2(const uint8_t *p) {
+  const __m256i x = _mm256_or_si256(_mm256_loadu_si256((const __m256i *)p), _mm256_set1_epi8(0x20));  // lower case
+  __m256i code = _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(3));                      // a0 c1 g3 t2
+  code = _mm256_xor_si256(code, _mm256_and_si256(_mm256_srli_epi16(code, 1), _mm256_set1_epi8(1)));  // a0 c1 g2 t3
+  const __m256i letters = _mm256_setr_epi8('a', 'c', 'g', 't', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'a', 'c', 'g', 't', 0, 0, 0,
+                                           0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i valid = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, code), x);  // anything else packs as A
+  code = _mm256_and_si256(code, valid);
+  // pairs: c0 * 4 + c1 (16-bit lanes), then quads: * 16 + next pair (32-bit lanes, one byte of four bases each)
+  const __m256i pairs = _mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0104));
+  const __m256i quads = _mm256_madd_epi16(pairs, _mm256_set1_epi32(0x00010010));
+  // the low byte of each 32-bit lane, last quad first, so that a little-endian load has the first base on top
+  const __m256i sh = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1,
+                                      -1, -1, -1, -1, -1, -1, -1);
+  const __m256i by = _mm256_shuffle_epi8(quads, sh);
+  const uint32_t hi = (uint32_t)_mm256_extract_epi32(by, 0), lo = (uint32_t)_mm256_extract_epi32(by, 4);
+  return ((uint64_t)hi << 32) | lo;
+}
+inline uint64_t pack_scalar(const uint8_t *p, uint32_t k) {  // k <= 32 bases, left-aligned
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint8_t x = p[i] | 0x20;
+    const uint64_t c = x == 'c' ? 1 : x == 'g' ? 2 : x == 't' ? 3 : 0;
+    w |= c << (62 - 2 * i);
+  }
+  return w;
+}
+__attribute__((target("avx2"))) void pack_reads_avx2(const uint8_t *bases, const uint64_t *off, uint64_t n, uint32_t stride,
+                                                     uint64_t *words, uint32_t *lens) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint8_t *p = bases + off[i];
+    const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
+    uint64_t *w = words + i * (uint64_t)stride;
+    uint32_t k = 0, d = 0;
+    for (; d + 32 <= len; d += 32) w[k++] = pack32_avx2(p + d);
+    if (d < len) {  // the last, partial word the same way: from a copy padded with 'A' (code 0 = the zero padding)
+      alignas(32) uint8_t tail[32];
+      memset(tail, 'A', 32);
+      memcpy(tail, p + d, len - d);
+      w[k++] = pack32_avx2(tail);
+    }
+    for (; k < stride; ++k) w[k] = 0;
+    lens[i] = len;
+  }
+}
+}  // namespace
+
+void pack_reads_2bit(const uint8_t *bases, const uint64_t *off, uint64_t n, uint32_t stride, uint64_t *words, uint32_t *lens) {
+  static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("NIMBLE_FASTQ_NO_AVX2") == nullptr;
+  if (avx2) return pack_reads_avx2(bases, off, n, stride, words, lens);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint8_t *p = bases + off[i];
+    const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
+    uint64_t *w = words + i * (uint64_t)stride;
+    uint32_t k = 0;
+    for (uint32_t d = 0; d < len; d += 32) w[k++] = pack_scalar(p + d, std::min<uint32_t>(32, len - d));
+    for (; k < stride; ++k) w[k] = 0;
+    lens[i] = len;
+  }
+}
+
+namespace {
+__attribute__((target("avx2"), always_inline)) inline size_t find_nl_avx2(const uint8_t *d, size_t from, size_t hard_end) {
+  // position of the next line terminator, or hard_end
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  size_t q = from;
+  while (q + 32 <= hard_end) {
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(d + q)), nlv));
+    if (m) return q + (size_t)__builtin_ctz(m);
+    q += 32;
+  }
+  for (; q < hard_end; ++q)
+    if (d[q] == '\n') return q;
+  return hard_end;
+}
+
+// Parse and pack in one pass, for a reader whose batches only travel packed: the ordinary record -- '@' line, ONE sequence
+// line, '+' line, one quality line, all four terminators inside the data -- is found with in-line 32-byte compares (memchr
+// costs more to call on a 13-byte header than it spends scanning it) and its bases go from the file text straight into
+// the batch's words; no ASCII copy is kept (data.bases stays empty, data.offsets holds the running lengths).  Records
+// starting in [p, limit) are taken while they have that shape and fit `stride` words; the position of the first that does
+// not (or >= limit) is returned, and the caller then does the whole range the general way.  A record must END before
+// hard_end - 1 (what follows it has to be visible, as in parse_records for a window that is not the end of the input).
+__attribute__((target("avx2"))) size_t parse_pack_avx2(const uint8_t *d, size_t p, size_t limit, size_t hard_end,
+                                                       uint32_t stride, BatchReader::Batch &b) {
+  FastqData &out = b.data;
+  uint64_t total = 0;
+  uint64_t n = 0;
+  while (p < limit) {
+    if (d[p] != '@') return p;
+    const size_t n1 = find_nl_avx2(d, p, hard_end);
+    if (n1 >= hard_end) return p;
+    const size_t s = n1 + 1;
+    if (s >= hard_end || d[s] == '+') return p;
+    const size_t n2 = find_nl_avx2(d, s, hard_end);
+    if (n2 + 1 >= hard_end || d[n2 + 1] != '+') return p;  // (a second sequence line, or the data ends)
+    const size_t n3 = find_nl_avx2(d, n2 + 1, hard_end);
+    if (n3 >= hard_end) return p;
+    const size_t n4 = find_nl_avx2(d, n3 + 1, hard_end);
+    if (n4 + 1 >= hard_end) return p;
+    size_t len = n2 - s;
+    if (len && d[s + len - 1] <= ' ') len = trimmed(d + s, len);  // (trailing blanks, a '\r': rare)
+    if (len > 32u * (size_t)stride) return p;
+    const uint64_t at = n * stride;
+    if (at + stride > b.words.capacity() || n + 1 > b.lens.capacity()) {
+      b.unpin();  // (the vectors move: see pack_batch)
+      b.words.reserve(std::max<uint64_t>(2 * b.words.capacity(), at + stride + 1024));
+      b.lens.reserve(std::max<uint64_t>(2 * b.lens.capacity(), n + 1024));
+    }
+    b.words.resize(at + stride);
+    uint64_t *w = b.words.data() + at;
+    uint32_t k = 0;
+    size_t dn = 0;
+    for (; dn + 32 <= len; dn += 32) w[k++] = pack32_avx2(d + s + dn);
+    if (dn < len) {
+      alignas(32) uint8_t tail[32];
+      memset(tail, 'A', 32);
+      memcpy(tail, d + s + dn, len - dn);
+      w[k++] = pack32_avx2(tail);
+    }
+    for (; k < stride; ++k) w[k] = 0;
+    b.lens.push_back((uint32_t)len);
+    total += len;
+    out.offsets.push_back(total);
+    if (len > out.max_len) out.max_len = (uint32_t)len;
+    ++n;
+    p = n4 + 1;
+  }
+  return p;
+}
+
+bool packing_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("NIMBLE_FASTQ_PACK");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
+// the packed form of a parsed batch (worker threads call this on their own chunk)
+void pack_batch(BatchReader::Batch &b) {
+  const bool on = packing_enabled();
+  b.stride = 0;
+  const uint64_t n = b.data.n();
+  if (!on || n == 0 || b.data.max_len == 0) return;
+  b.stride = (b.data.max_len + 31u) / 32u;
+  const uint64_t nw = n * (uint64_t)b.stride;
+  if (nw > b.words.capacity() || n > b.lens.capacity()) {
+    // the vectors are about to move: their page-lock registration must not outlive the memory it names (the allocator
+    // hands a freed block to another batch, whose own registration -- or a copy from it -- then collides with the stale one)
+    b.unpin();
+    b.words.reserve(nw + nw / 4);
+    b.lens.reserve(n + n / 4);
+  }
+  b.words.resize(nw);
+  b.lens.resize(n);
+  pack_reads_2bit(b.data.bases.data(), b.data.offsets.data(), n, b.stride, b.words.data(), b.lens.data());
+}
+}  // namespace
+
 // Page-lock the batch's buffers for the device copy.  A recycled batch keeps its registration as long as its vectors
 // have not been re-allocated; pinning is best effort (pageable memory still works, only slower).
 void BatchReader::Batch::pin() {
   static const bool off = getenv("NIMBLE_FASTQ_NO_PIN") != nullptr;
   if (off) return;
+  // what travels: the packed words and lengths when the batch has them, else the ASCII bases and their offsets
   void *want[2] = {data.bases.capacity() ? (void *)data.bases.data() : nullptr,
                    data.offsets.capacity() ? (void *)data.offsets.data() : nullptr};
-  const uint64_t bytes[2] = {data.bases.capacity(), data.offsets.capacity() * sizeof(uint64_t)};
+  uint64_t bytes[2] = {data.bases.capacity(), data.offsets.capacity() * sizeof(uint64_t)};
+  if (stride) {
+    want[0] = words.capacity() ? (void *)words.data() : nullptr;
+    want[1] = lens.capacity() ? (void *)lens.data() : nullptr;
+    bytes[0] = words.capacity() * sizeof(uint64_t);
+    bytes[1] = lens.capacity() * sizeof(uint32_t);
+  }
   for (int k = 0; k < 2; ++k) {
     if (pinned[k] == want[k]) continue;
     if (pinned[k]) nimble_pinned_unregister(pinned[k]);
     pinned[k] = nullptr;
-    if (want[k] && bytes[k] >= (1u << 20) && nimble_pinned_register(want[k], bytes[k]) == 0) pinned[k] = want[k];
+    if (want[k] && bytes[k] >= (64u << 10) && nimble_pinned_register(want[k], bytes[k]) == 0) pinned[k] = want[k];
   }
 }
 void BatchReader::Batch::unpin() {
@@ -219,15 +390,17 @@ class ParallelPlain {
   };
   // the same parser over a window of memory [d + from, d + n): `final` = the input ends with it; otherwise the record that
   // runs into the end of the window is left alone (carry_from() says where it starts) and no batch is the last
-  ParallelPlain(const uint8_t *d, size_t from, size_t n, bool is_mate, bool final, std::shared_ptr<Pool> pool)
-      : is_mate_(is_mate), final_(final), shared_(std::move(pool)) {
+  ParallelPlain(const uint8_t *d, size_t from, size_t n, bool is_mate, bool final, std::shared_ptr<Pool> pool, bool packed,
+                uint32_t stride_hint = 0)
+      : is_mate_(is_mate), packed_(packed), final_(final), shared_(std::move(pool)) {
+    stride_hint_ = stride_hint;
     data_ = d;
     size_ = n;
     base_ = from;
     true_start_ = from;
     start_workers();
   }
-  ParallelPlain(const std::string &path, bool is_mate) : is_mate_(is_mate) {
+  ParallelPlain(const std::string &path, bool is_mate, bool packed) : is_mate_(is_mate), packed_(packed) {
     fd_ = open(path.c_str(), O_RDONLY);
     if (fd_ < 0) throw Panic("Error -- could not determine compression format for " + path);
     struct stat st;
@@ -270,6 +443,7 @@ class ParallelPlain {
     if (mapped_) munmap((void *)data_, size_);
     if (fd_ >= 0) close(fd_);
   }
+  uint32_t stride_hint() const { return stride_hint_.load(std::memory_order_relaxed); }
   size_t carry_from() const { return true_start_; }  // (after the last batch) where the unparsed tail of the window starts
   static bool is_plain(const std::string &path) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -366,6 +540,45 @@ class ParallelPlain {
 
   // records starting in [start, limit)
   void parse_range(size_t start, size_t limit, Batch &b) const {
+    b.stride = 0;
+    if (!packed_) return parse_records(start, limit, b);
+    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("NIMBLE_FASTQ_NO_AVX2") == nullptr;
+    if (avx2 && start < limit) {
+      // one pass from the file text to the words; the stride is that of the reads seen so far (the first record when none)
+      uint32_t stride = stride_hint_.load(std::memory_order_relaxed);
+      if (stride == 0) {
+        MemLines probe(data_, start, size_);
+        const uint8_t *l;
+        size_t len = 0;
+        if (probe.next(l, len) && probe.next(l, len)) stride = (uint32_t)std::min<size_t>((trimmed(l, len) + 31) / 32, 1u << 20);
+      }
+      if (stride) {
+        b.data.bases.clear();
+        b.data.offsets.assign(1, 0);
+        b.data.max_len = 0;
+        b.error.clear();
+        b.words.clear();
+        b.lens.clear();
+        b.start = start;
+        const size_t q = parse_pack_avx2(data_, start, limit, size_, stride, b);
+        if (q >= limit) {
+          b.end = std::max(q, start);
+          b.stride = b.data.n() ? stride : 0;
+          uint32_t seen = stride_hint_.load(std::memory_order_relaxed);
+          while (b.stride > seen && !stride_hint_.compare_exchange_weak(seen, b.stride, std::memory_order_relaxed)) {
+          }
+          return;
+        }
+      }
+    }
+    // something in the range is no ordinary record (or is longer than the stride, or ends the data): the general way
+    parse_records(start, limit, b);
+    pack_batch(b);
+    uint32_t seen = stride_hint_.load(std::memory_order_relaxed);
+    while (b.stride > seen && !stride_hint_.compare_exchange_weak(seen, b.stride, std::memory_order_relaxed)) {
+    }
+  }
+  void parse_records(size_t start, size_t limit, Batch &b) const {
     b.data.bases.clear();
     b.data.offsets.assign(1, 0);
     b.data.max_len = 0;
@@ -418,6 +631,8 @@ class ParallelPlain {
   }
 
   bool is_mate_;
+  bool packed_ = false;  // batches travel packed (BatchReader's `packed`): words and lengths, no ASCII copy where avoidable
+  mutable std::atomic<uint32_t> stride_hint_{0};
   bool final_ = true, mapped_ = false;
   std::shared_ptr<Pool> shared_;
   int fd_ = -1;
@@ -436,7 +651,8 @@ class ParallelPlain {
 class ParallelGz {
  public:
   typedef BatchReader::Batch Batch;
-  ParallelGz(const std::string &path, bool is_mate) : is_mate_(is_mate), pool_(new ParallelPlain::Pool()) {
+  ParallelGz(const std::string &path, bool is_mate, bool packed)
+      : is_mate_(is_mate), packed_(packed), pool_(new ParallelPlain::Pool()) {
     unsigned t = std::min(parse::usable_cpus(), 32u);
     if (const char *e = getenv("NIMBLE_GZIP_THREADS")) t = (unsigned)std::max(1, atoi(e));
     threads_ = t;
@@ -477,7 +693,7 @@ class ParallelGz {
         memcpy(w->buf.data() + w->head - carry_.size(), carry_.data(), carry_.size());
         const size_t from = w->head - carry_.size();
         win_ = std::move(w);
-        cur_.reset(new ParallelPlain(win_->buf.data(), from, win_->buf.size(), is_mate_, win_->final, pool_));
+        cur_.reset(new ParallelPlain(win_->buf.data(), from, win_->buf.size(), is_mate_, win_->final, pool_, packed_, stride_hint_));
       }
       if (!cur_->done()) {
         std::unique_ptr<Batch> b = cur_->next();
@@ -485,6 +701,7 @@ class ParallelGz {
         return b;
       }
       const size_t cf = cur_->carry_from();
+      stride_hint_ = std::max(stride_hint_, cur_->stride_hint());
       carry_.assign(win_->buf.data() + std::min(cf, win_->buf.size()), win_->buf.data() + win_->buf.size());
       const bool was_final = win_->final;
       cur_.reset();
@@ -619,6 +836,8 @@ class ParallelGz {
   }
 
   bool is_mate_;
+  bool packed_ = false;
+  uint32_t stride_hint_ = 0;  // words a read of the windows parsed so far (the next window's parser starts from it)
   std::shared_ptr<ParallelPlain::Pool> pool_;
   unsigned threads_ = 1;
   size_t target_ = 0;
@@ -704,18 +923,18 @@ struct BatchReader::Impl {
   }
 };
 
-BatchReader::BatchReader(const std::string &path, bool is_mate, size_t batch_reads) : impl_(new Impl()) {
+BatchReader::BatchReader(const std::string &path, bool is_mate, size_t batch_reads, bool packed) : impl_(new Impl()) {
   impl_->path = path;
   impl_->is_mate = is_mate;
   impl_->batch_reads = std::max<size_t>(batch_reads, 1);
   static const bool serial = getenv("NIMBLE_FASTQ_SERIAL") != nullptr;
   if (!serial && ParallelPlain::is_plain(path)) {
-    impl_->plain.reset(new ParallelPlain(path, is_mate));
+    impl_->plain.reset(new ParallelPlain(path, is_mate, packed && packing_enabled()));
     return;
   }
   const bool serial_gz = getenv("NIMBLE_GZIP_SERIAL") != nullptr;
   if (!serial && !serial_gz) {
-    impl_->gz.reset(new ParallelGz(path, is_mate));
+    impl_->gz.reset(new ParallelGz(path, is_mate, packed && packing_enabled()));
     return;
   }
   for (int i = 0; i < 3; ++i) impl_->spare.emplace_back(new Batch());
@@ -784,7 +1003,7 @@ struct Cursor {
   // untouched until the second following append has returned), so a batch goes back to the reader two steps late
   std::unique_ptr<parse::fastq::BatchReader::Batch> held, held2;
   uint64_t used = 0;
-  Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads) {}
+  Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads, true) {}
   uint64_t avail() const { return b ? b->data.n() - used : 0; }
   bool at_end() const { return b && b->last && used == b->data.n(); }  // the file's event (EOF or bad record) is next
   void fill() {  // make records available unless the file is at its event
@@ -852,12 +1071,22 @@ void streamed(const std::vector<std::string> &input_files,
       a.n = n;
       a.max_len = c1.b->data.max_len;
       a.pinned = c1.b->pinned[0] != nullptr;  // (the small offsets array may be pageable: HIP stages such a copy before it returns)
+      if (c1.b->stride && a.pinned) {
+        a.words = c1.b->words.data() + c1.used * (uint64_t)c1.b->stride;
+        a.lens = c1.b->lens.data() + c1.used;
+        a.stride = c1.b->stride;
+      }
       if (paired) {
         m.bases = c2->b->data.bases.data();
         m.offsets = c2->b->data.offsets.data() + c2->used;
         m.n = n;
         m.max_len = c2->b->data.max_len;
         m.pinned = c2->b->pinned[0] != nullptr;
+        if (c2->b->stride && m.pinned) {
+          m.words = c2->b->words.data() + c2->used * (uint64_t)c2->b->stride;
+          m.lens = c2->b->lens.data() + c2->used;
+          m.stride = c2->b->stride;
+        }
       }
       const auto ta = now();
       for (auto &st : streams) st->append(a, paired ? &m : nullptr);

@@ -509,6 +509,17 @@ int nimble_host_pgzip_decompress(const char *path, int threads, const char *out_
   });
 }
 
+int nimble_host_pack_reads_2bit(const uint8_t *bases, const uint64_t *off, uint64_t n, uint32_t stride, uint64_t *words,
+                                uint32_t *lens) {
+  return guarded([&] {
+    if (n && (!bases || !off || !words || !lens || stride == 0)) throw Panic("nimble_host_pack_reads_2bit: bad argument");
+    for (uint64_t i = 0; i < n; ++i)
+      if (off[i + 1] < off[i] || off[i + 1] - off[i] > 32ULL * stride)
+        throw Panic("nimble_host_pack_reads_2bit: a read does not fit its words");
+    parse::fastq::pack_reads_2bit(bases, off, n, stride, words, lens);
+  });
+}
+
 int nimble_host_reverse_comp_if_needed(const char *seq, int reverse_comp, char *out, uint64_t cap) {
   return guarded([&] {
     const std::string r = process::bam::reverse_comp_if_needed(seq, reverse_comp != 0);
@@ -595,6 +606,40 @@ int nimble_host_read_fastq_batched(const char *path, uint64_t batch_reads, uint6
         h = (h ^ (b->data.offsets[i + 1] - b->data.offsets[i])) * 1099511628211ULL;
         for (uint64_t k = b->data.offsets[i]; k < b->data.offsets[i + 1]; ++k)
           h = (h ^ b->data.bases[k]) * 1099511628211ULL;
+      }
+      if (!b->error.empty()) {
+        if (checksum) *checksum = h;
+        throw Panic(b->error);
+      }
+      if (b->last) break;
+      rd.recycle(std::move(b));
+    }
+    if (checksum) *checksum = h;
+  });
+}
+int nimble_host_read_fastq_packed(const char *path, uint64_t batch_reads, uint64_t *n, uint64_t *bases, uint32_t *max_len,
+                                  uint64_t *n_batches, uint64_t *checksum) {
+  return guarded([&] {
+    parse::fastq::BatchReader rd(path, false, (size_t)batch_reads, true);
+    *n = *bases = *n_batches = 0;
+    *max_len = 0;
+    uint64_t h = 1469598103934665603ULL;
+    for (;;) {
+      std::unique_ptr<parse::fastq::BatchReader::Batch> b = rd.next();
+      const uint64_t m = b->data.n();
+      if (m && b->stride == 0) throw Panic("nimble_host_read_fastq_packed: a batch came without its packed form");
+      *n += m;
+      *max_len = std::max(*max_len, b->data.max_len);
+      ++*n_batches;
+      for (uint64_t i = 0; i < m; ++i) {  // FNV over (length, bases) of every record, bases as the words spell them
+        const uint32_t len = b->lens[i];
+        if (len != b->data.offsets[i + 1] - b->data.offsets[i]) throw Panic("nimble_host_read_fastq_packed: lengths disagree");
+        *bases += len;
+        h = (h ^ len) * 1099511628211ULL;
+        const uint64_t *w = b->words.data() + i * (uint64_t)b->stride;
+        for (uint32_t k = 0; k < len; ++k) h = (h ^ (uint64_t)"ACGT"[(w[k >> 5] >> (62 - 2 * (k & 31))) & 3]) * 1099511628211ULL;
+        for (uint32_t k = len; k < 32u * b->stride; ++k)
+          if ((w[k >> 5] >> (62 - 2 * (k & 31))) & 3) throw Panic("nimble_host_read_fastq_packed: bits behind the last base");
       }
       if (!b->error.empty()) {
         if (checksum) *checksum = h;

@@ -163,7 +163,11 @@ struct ReadBatch {
   uint32_t fixed_len = 0;
   uint32_t max_len = 0;
   bool device = false;
-  bool pinned = false;  // page-locked host buffers the caller keeps untouched until the next append has returned
+  bool pinned = false;  // page-locked host buffers the caller keeps untouched until the next append but one has returned
+  // the same reads packed by the host (parse::fastq::pack_reads_2bit); when set, a stream sends these instead of `bases`
+  const uint64_t *words = nullptr;
+  const uint32_t *lens = nullptr;
+  uint32_t stride = 0;
 };
 
 // One row of the result: (callset, (count, metadata, metadata)); metadata is empty on the FASTQ path
@@ -305,6 +309,10 @@ struct FastqData {
 // Panics with "Error -- could not parse read. Input R1 data malformed." (src/align.rs:517) /
 // "... reverse read. Input R2 data malformed." (src/align.rs:541) on a malformed record.
 FastqData read_fastq(const std::string &path, bool is_mate);
+// n reads (ASCII at bases + off[i] .. off[i + 1]) as 2-bit words: read i in words[i * stride ..], first base in the highest
+// bit pair of word 0, A=0 C=1 G=2 T=3 in either case, any other byte as A (DnaString::from_acgt_bytes), zero bits behind the
+// last base; lens[i] = its length.  stride * 32 must hold the longest read.
+void pack_reads_2bit(const uint8_t *bases, const uint64_t *off, uint64_t n, uint32_t stride, uint64_t *words, uint32_t *lens);
 // The same, the way the reference's lazy iterators behave: at most `max_records` records are read, and a malformed record
 // ends the read with its panic text in *error (empty when none) instead of panicking here.
 FastqData read_fastq_lazy(const std::string &path, bool is_mate, uint64_t max_records, std::string *error);
@@ -322,13 +330,21 @@ class BatchReader {
     std::string error;        // panic text of the malformed record that follows data, if any
     uint64_t raw_offset = 0;  // (compressed) file bytes consumed when the batch was closed
     uint64_t start = 0, end = 0;  // byte range of the records (plain files parsed in parallel chunks)
-    // the two buffers stay page-locked while the batch object is re-used (full-rate asynchronous H2D)
+    // The reads once more, packed for the link to the device (include/nimble_hip.h: nimble_stream_append_packed): read i is
+    // lens[i] bases in words[i * stride .. (i + 1) * stride), 32 bases a word.  stride == 0: not packed (the one-thread
+    // readers, NIMBLE_FASTQ_PACK=0); the consumer then sends data.bases.
+    std::vector<uint64_t> words;
+    std::vector<uint32_t> lens;
+    uint32_t stride = 0;
+    // the two buffers that travel stay page-locked while the batch object is re-used (full-rate asynchronous H2D)
     void *pinned[2] = {nullptr, nullptr};
     void pin();
     void unpin();
     ~Batch() { unpin(); }
   };
-  BatchReader(const std::string &path, bool is_mate, size_t batch_reads);
+  // packed: the batches are for nimble_stream_append_packed -- words and lens are filled (stride > 0), and where the file
+  // allows it the ASCII copy is not made at all (data.bases empty, data.offsets the running lengths)
+  BatchReader(const std::string &path, bool is_mate, size_t batch_reads, bool packed = false);
   ~BatchReader();
   std::unique_ptr<Batch> next();            // blocks until the next batch is parsed
   void recycle(std::unique_ptr<Batch> b);  // hand the buffers back for reuse

@@ -396,6 +396,88 @@ def test_fastq_pipeline_streams_batches(synth_lib, tmp_path, monkeypatch):
     assert open(out).read() == "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in exp)
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_stream_append_packed_equals_ascii_append(synth_lib, paired):
+    # nimble_stream_append_packed (reads packed to 2 bits by the host's parser threads) against nimble_stream_append on
+    # the same reads: ragged lengths (0 .. 151, word boundaries), lower case, N and other foreign bytes (packed as A, as
+    # k_pack treats them), mates whose lengths make the key straddle words.  Every per-read record, the histogram and the
+    # work counters must be the same; batches of both forms mix in one stream.
+    path, seqs = synth_lib
+    rng = np.random.default_rng(11 + int(paired))
+    n = 30_000
+    base = synth.make_reads(seqs, n, seed=901)
+    mate = synth.make_reads(seqs, n, seed=902)
+
+    def ragged(reads, seed):
+        r = np.random.default_rng(seed)
+        lens = r.integers(0, 152, size=n)
+        lens[:8] = [0, 1, 31, 32, 33, 64, 150, 151]
+        out = []
+        for i in range(n):
+            b = bytearray(bytes(reads[i, :min(lens[i], 150)]) + (b"A" if lens[i] == 151 else b""))
+            if i % 7 == 0 and b:
+                b[int(r.integers(0, len(b)))] = ord("N")
+            if i % 11 == 0:
+                b = bytearray(bytes(b).lower())
+            if i % 13 == 0 and b:
+                b[int(r.integers(0, len(b)))] = ord("*")
+            out.append(bytes(b))
+        return out
+
+    s1 = ragged(base, 1)
+    s2 = ragged(mate, 2) if paired else None
+    idx = nim.Library(path, "unstranded").build_index()
+    ctx = idx.device_context()
+    cfg = nim.AlignParams.make(0.33, 50, 0, require_valid_pair=paired)
+    ctx.set_counters(True)
+
+    def run(form):
+        ctx.stream_begin(cfg, paired, 160, capacity_hint=1000)
+        keep = []
+        for k, a in enumerate(range(0, n, 7001)):
+            b = min(n, a + 7001)
+            packed = form == "packed" or (form == "mixed" and k % 2 == 0)
+            if packed:
+                w1, l1, st1 = nim.pack_reads_2bit(s1[a:b], 5 if k % 2 else None)
+                if paired:
+                    w2, l2, st2 = nim.pack_reads_2bit(s2[a:b])
+                    ctx.stream_append_packed(w1, l1, st1, w2, l2, st2)
+                else:
+                    ctx.stream_append_packed(w1, l1, st1)
+            else:
+                f1, o1 = nim.pack_reads(s1[a:b])
+                if paired:
+                    f2, o2 = nim.pack_reads(s2[a:b])
+                    ctx.stream_append(f1, o1, f2, o2)
+                    keep.append((f2, o2))
+                else:
+                    ctx.stream_append(f1, o1)
+                keep.append((f1, o1))
+        ctx.stream_end()
+        recs = [ctx.read_records(m) for m in range(2 if paired else 1)]
+        return recs, ctx.histogram(), ctx.counters()
+
+    want = run("ascii")
+    assert want[2]["reads"] == n and want[2]["seeded"] > n // 4
+    for form in ("packed", "mixed"):
+        got = run(form)
+        for m in range(2 if paired else 1):
+            for key in ("reason", "score", "mismatches", "cls", "counted"):
+                np.testing.assert_array_equal(got[0][m][key], want[0][m][key], err_msg="%s %s mate %d" % (form, key, m))
+        assert got[1] == want[1]
+        # (dynamic_classes counts the classes interned BY this call: the first run interned them for the index)
+        assert {k: v for k, v in got[2].items() if k != "dynamic_classes"} == \
+               {k: v for k, v in want[2].items() if k != "dynamic_classes"}
+    # a read longer than its words, or than the stream: refused on the host
+    w, l, st = nim.pack_reads_2bit([b"ACGT" * 50])
+    ctx.stream_begin(cfg, False, 160)
+    try:
+        with pytest.raises(nim.NimbleError, match="longer than"):
+            ctx.stream_append_packed(w, np.array([st * 32 + 1], dtype=np.uint32), st)
+    finally:
+        ctx.stream_end()
+
+
 @pytest.mark.parametrize("batch", ["0", "300"])
 def test_fastq_pull_order_and_blank_quality_line(synth_lib, tmp_path, monkeypatch, batch):
     # The reference pulls R1 record i, then R2 record i (align.rs:511-541), so (a) R2 is never read beyond R1's last

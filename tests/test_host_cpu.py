@@ -392,3 +392,91 @@ def test_synthetic_generator_is_deterministic():
     assert np.array_equal(a, b) and a.shape == (500, 150)
     r1, r2 = synth.make_reads(s1, 300, paired=True)
     assert r1.shape == r2.shape == (300, 150)
+
+
+def test_host_2bit_packer_against_a_plain_restatement():
+    # parse::fastq::pack_reads_2bit (AVX2 on the box, scalar elsewhere): 32 bases a word, first base on top, either case,
+    # anything that is no A/C/G/T as A (DnaString::from_acgt_bytes), zero bits behind the last base
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTacgtNn-*RY", dtype=np.uint8)
+    reads = [bytes(alphabet[rng.integers(0, len(alphabet), int(L))]) for L in
+             list(rng.integers(0, 200, 300)) + [0, 1, 31, 32, 33, 63, 64, 65, 150, 151]]
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("a"): 0, ord("c"): 1, ord("g"): 2, ord("t"): 3}
+    for stride in (None, 9):
+        words, lens, st = nim.pack_reads_2bit(reads, stride)
+        assert st == (stride or 7) and list(lens) == [len(r) for r in reads]
+        for i, r in enumerate(reads):
+            want = [0] * st
+            for j, c in enumerate(r):
+                want[j >> 5] |= code.get(c, 0) << (62 - 2 * (j & 31))
+            assert [int(w) for w in words[i * st:(i + 1) * st]] == want, (i, r)
+    with pytest.raises(nim.Panic, match="does not fit"):
+        nim.pack_reads_2bit([b"A" * 65], 2)
+
+
+def _spell(r):
+    # what the packed words say of a read: upper case, anything that is no A/C/G/T as A
+    t = bytes.maketrans(b"acgt", b"ACGT")
+    return bytes(c if c in b"ACGT" else ord("A") for c in r.translate(t))
+
+
+def test_packed_batch_reader_same_records_as_the_line_reader(tmp_path, monkeypatch):
+    # the reader in the mode the FASTQ pipeline runs it in (fused parse + 2-bit pack, no ASCII copy): the records of the
+    # line reader, spelt by the words, for plain and gzip input, any chunk size, ordinary and odd records, ragged lengths
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(6000):
+        L = int(rng.integers(0, 200)) if i % 50 else 150
+        r = bytes(rng.choice(list(b"ACGTNacgtn"), size=L, p=[0.22, 0.22, 0.22, 0.22, 0.02, 0.02, 0.02, 0.02, 0.02, 0.02])
+                  .astype(np.uint8))
+        recs.append(r)
+    recs[17] = b""
+    text = b"".join(b"@r%d some description\n%s\n+\n%s\n" % (i, r, b"F" * max(len(r), 1)) for i, r in enumerate(recs))
+    plain = tmp_path / "x.fastq"
+    plain.write_bytes(text)
+    want = (len(recs), sum(map(len, recs)), max(map(len, recs)), _fnv_records([_spell(r) for r in recs]))
+    for chunk, threads in ((64, 3), (997, 8), (4096, 4), (1 << 16, 2), (1 << 30, 4)):
+        monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", str(chunk))
+        monkeypatch.setenv("NIMBLE_FASTQ_THREADS", str(threads))
+        got = nim.read_fastq_packed_stats(str(plain), 1000)
+        assert (got[0], got[1], got[2], got[4]) == want, (chunk, threads)
+    monkeypatch.setenv("NIMBLE_FASTQ_NO_AVX2", "1")   # the general way only (parse, then pack)
+    got = nim.read_fastq_packed_stats(str(plain), 1000)
+    assert (got[0], got[1], got[2], got[4]) == want
+    monkeypatch.delenv("NIMBLE_FASTQ_NO_AVX2")
+    gz = tmp_path / "x.fastq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(text)
+    monkeypatch.setenv("NIMBLE_GZIP_WINDOW", "200000")
+    monkeypatch.setenv("NIMBLE_GZIP_CHUNK", "65536")
+    got = nim.read_fastq_packed_stats(str(gz), 1000)
+    assert (got[0], got[1], got[2], got[4]) == want
+    # records that are not of the ordinary shape: two sequence lines, qualities that start with '@' or '+', CRLF, and a
+    # longer read appearing late (the stride grows)
+    parts, odd = [], []
+    for i in range(2000):
+        r = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 120))).astype(np.uint8))
+        q = bytes(rng.choice(list(b"@+I#"), size=len(r)).astype(np.uint8))
+        if i % 5 == 0:
+            h = len(r) // 2
+            parts.append(b"@m%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:h], r[h:], q[:h] or b"I", q[h:] or b"I"))
+        elif i % 7 == 0:
+            parts.append(b"@c%d\r\n%s\r\n+\r\n%s\r\n" % (i, r, q))
+        else:
+            parts.append(b"@s%d\n%s\n+\n%s\n" % (i, r, q))
+        odd.append(r)
+    long_read = b"ACGT" * 100
+    parts.append(b"@long\n" + long_read + b"\n+\n" + b"I" * 400 + b"\n")
+    odd.append(long_read)
+    tricky = tmp_path / "tricky.fastq"
+    tricky.write_bytes(b"".join(parts))
+    want = (len(odd), sum(map(len, odd)), 400, _fnv_records(odd))
+    for chunk in (64, 333, 5000, 1 << 30):
+        monkeypatch.setenv("NIMBLE_FASTQ_CHUNK", str(chunk))
+        got = nim.read_fastq_packed_stats(str(tricky), 100)
+        assert (got[0], got[1], got[2], got[4]) == want, chunk
+    # a malformed record still ends the file with the reference's panic
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@a\nAC\n+\nII\n@b\nGG\n+\nII\nnot a header\nAC\n+\nII\n")
+    with pytest.raises(nim.Panic, match="Input R1 data malformed.: Unable to read sequence"):
+        nim.read_fastq_packed_stats(str(bad), 2)
