@@ -867,6 +867,7 @@ struct BatchReader::Impl {
   std::condition_variable cv;
   std::deque<std::unique_ptr<Batch>> ready, spare;
   bool stop = false;
+  bool packed = false;  // the one-thread reader packs its batches too (they keep their ASCII copy)
 
   void run() {
     std::unique_ptr<Batch> cur;
@@ -879,6 +880,7 @@ struct BatchReader::Impl {
       return b;
     };
     auto publish = [&](std::unique_ptr<Batch> b) {
+      if (packed) pack_batch(*b);
       std::lock_guard<std::mutex> lk(mu);
       ready.push_back(std::move(b));
       cv.notify_all();
@@ -927,6 +929,7 @@ BatchReader::BatchReader(const std::string &path, bool is_mate, size_t batch_rea
   impl_->path = path;
   impl_->is_mate = is_mate;
   impl_->batch_reads = std::max<size_t>(batch_reads, 1);
+  impl_->packed = packed && packing_enabled();
   static const bool serial = getenv("NIMBLE_FASTQ_SERIAL") != nullptr;
   if (!serial && ParallelPlain::is_plain(path)) {
     impl_->plain.reset(new ParallelPlain(path, is_mate, packed && packing_enabled()));
@@ -1003,7 +1006,7 @@ struct Cursor {
   // untouched until the second following append has returned), so a batch goes back to the reader two steps late
   std::unique_ptr<parse::fastq::BatchReader::Batch> held, held2;
   uint64_t used = 0;
-  Cursor(const std::string &path, bool is_mate, size_t batch_reads) : rd(path, is_mate, batch_reads, true) {}
+  Cursor(const std::string &path, bool is_mate, size_t batch_reads, bool packed) : rd(path, is_mate, batch_reads, packed) {}
   uint64_t avail() const { return b ? b->data.n() - used : 0; }
   bool at_end() const { return b && b->last && used == b->data.n(); }  // the file's event (EOF or bad record) is next
   void fill() {  // make records available unless the file is at its event
@@ -1025,9 +1028,9 @@ void streamed(const std::vector<std::string> &input_files,
               const std::vector<align::AlignFilterConfig> &aligner_configs,
               const std::vector<std::string> &output_paths, size_t batch_reads) {
   const bool paired = input_files.size() > 1;
-  Cursor c1(input_files.at(0), false, batch_reads);
+  Cursor c1(input_files.at(0), false, batch_reads, true);  // (batches travel packed: nimble_stream_append_packed)
   std::unique_ptr<Cursor> c2;
-  if (paired) c2.reset(new Cursor(input_files[1], true, batch_reads));
+  if (paired) c2.reset(new Cursor(input_files[1], true, batch_reads, true));
 
   std::vector<std::unique_ptr<align::CallStream>> streams;
   uint32_t stream_max_len = 0;
@@ -1071,7 +1074,7 @@ void streamed(const std::vector<std::string> &input_files,
       a.n = n;
       a.max_len = c1.b->data.max_len;
       a.pinned = c1.b->pinned[0] != nullptr;  // (the small offsets array may be pageable: HIP stages such a copy before it returns)
-      if (c1.b->stride && a.pinned) {
+      if (c1.b->stride) {  // (page-locked or not: a pageable buffer is copied before the append returns)
         a.words = c1.b->words.data() + c1.used * (uint64_t)c1.b->stride;
         a.lens = c1.b->lens.data() + c1.used;
         a.stride = c1.b->stride;
@@ -1082,7 +1085,7 @@ void streamed(const std::vector<std::string> &input_files,
         m.n = n;
         m.max_len = c2->b->data.max_len;
         m.pinned = c2->b->pinned[0] != nullptr;
-        if (c2->b->stride && m.pinned) {
+        if (c2->b->stride) {
           m.words = c2->b->words.data() + c2->used * (uint64_t)c2->b->stride;
           m.lens = c2->b->lens.data() + c2->used;
           m.stride = c2->b->stride;
@@ -1244,9 +1247,9 @@ void process_sharded(const std::vector<std::string> &input_files,
     uint32_t max_len = 0;
     for (;;) {  // (again from the start if a later batch holds a read longer than the call was opened for)
       bool too_long = false;
-      Cursor c1(input_files.at(0), false, batch);
+      Cursor c1(input_files.at(0), false, batch, false);  // (the sharded append takes ASCII)
       std::unique_ptr<Cursor> c2;
-      if (paired) c2.reset(new Cursor(input_files[1], true, batch));
+      if (paired) c2.reset(new Cursor(input_files[1], true, batch, false));
       bool begun = false;
       for (;;) {
         c1.fill();

@@ -25,7 +25,10 @@ def run(tag, env, reps=3):
     print("%-40s pipeline s %s  best %.1f M reads/s" % (tag, " ".join("%.3f" % t for t in ts), N / 1e6 / min(ts)), flush=True)
     if cons: print("      " + cons[-1], flush=True)
 run("defaults", {})
-run("4 parser threads", {"NIMBLE_FASTQ_THREADS": "4"})
-run("16 MiB chunks", {"NIMBLE_FASTQ_CHUNK": str(16 << 20)})
+run("buffers not page-locked", {"NIMBLE_FASTQ_NO_PIN": "1"})
+run("12 parser threads", {"NIMBLE_FASTQ_THREADS": "12"})
+run("14 parser threads", {"NIMBLE_FASTQ_THREADS": "14"})
+run("20 parser threads", {"NIMBLE_FASTQ_THREADS": "20"})
+run("ASCII batches (no host packing)", {"NIMBLE_FASTQ_PACK": "0"})
 subprocess.run(["rm", "-rf", d])
 PY
