@@ -130,6 +130,7 @@ struct nimble_ctx {
   hipEvent_t ev_h2d[2] = {}, ev_used[2] = {};
   bool stage_busy[2] = {false, false};
   int stage_k = 0;
+  uint64_t align_from = 0;  // streamed call: first appended read the align kernel has not been launched for yet
   bool h2d_pending[2] = {false, false};  // staging slots whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
@@ -1482,6 +1483,7 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   c->stage_busy[0] = c->stage_busy[1] = false;
   c->stage_k = 0;
   c->h2d_pending[0] = c->h2d_pending[1] = false;
+  c->align_from = 0;
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->defer.active = false;
   c->defer.world = 0;
@@ -1490,6 +1492,45 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   c->streaming = true;
   c->finished = true;  // nothing to fetch until nimble_stream_end
   c->called = false;
+  return NIMBLE_OK;
+}
+
+// the call arrays as one batch of a streamed call sees them: reads [from, from + count)
+static CallBuffers stream_view(const nimble_ctx *c, uint64_t from, uint64_t count) {
+  CallBuffers v = c->cb;
+  v.n = count;
+  v.key_stride = c->stream_cap;
+  v.keys += from;
+  v.key_hash += from;
+  v.slot += from;
+  v.counted += from;
+  for (int mt = 0; mt < 2; ++mt) {
+    v.len[mt] += from;
+    v.alen[mt] += from;  // aliases len (a streamed call does not trim)
+    v.pre[mt] += from;
+    v.reason[mt] += from;
+    v.score[mt] += from;
+    v.mism[mt] += from;
+    v.cls[mt] += from;
+    v.dyn_off[mt] += from;
+    v.dyn_len[mt] += from;
+    v.dyn_hash[mt] += from;
+    v.dyn_pos[mt] += from;
+  }
+  return v;
+}
+
+// The align kernel of a streamed call runs over everything packed since its last launch, once that is worth a launch
+// (a persistent grid over a 25 k-read batch is mostly launch and drain: 40 us for 10 us of work, and with the batches
+// arriving packed that was what the stream waited for) or when the stream ends.
+constexpr uint64_t STREAM_ALIGN_READS = 1u << 18;
+static int stream_flush_align(nimble_ctx *c, bool force) {
+  const uint64_t pending = c->stream_n - c->align_from;
+  if (pending == 0 || (!force && pending < STREAM_ALIGN_READS)) return NIMBLE_OK;
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
+  launch_align(c->stream, c->ix->dev, c->prm, stream_view(c, c->align_from, pending), c->want_counters, c->align_grid_pct);
+  HIPCHK(hipGetLastError());
+  c->align_from = c->stream_n;
   return NIMBLE_OK;
 }
 
@@ -1552,44 +1593,19 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
     HIPCHK(hipEventRecord(c->ev_h2d[k], c->h2d_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[k], 0));
   }
-  // the batch's view of the call arrays
-  CallBuffers v = c->cb;
-  const uint64_t B = c->stream_n;
-  v.n = m;
-  v.key_stride = c->stream_cap;
-  v.keys += B;
-  v.key_hash += B;
-  v.slot += B;
-  v.counted += B;
-  for (int mt = 0; mt < 2; ++mt) {
-    v.len[mt] += B;
-    v.alen[mt] += B;  // aliases len (a streamed call does not trim)
-    v.pre[mt] += B;
-    v.reason[mt] += B;
-    v.score[mt] += B;
-    v.mism[mt] += B;
-    v.cls[mt] += B;
-    v.dyn_off[mt] += B;
-    v.dyn_len[mt] += B;
-    v.dyn_hash[mt] += B;
-    v.dyn_pos[mt] += B;
-  }
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
+  const CallBuffers v = stream_view(c, c->stream_n, m);
   launch_pack(c->stream, in_r[0], in_off[0], in_r[1], in_off[1], fixed_len, max_len, c->prm.min_read_length,
               c->b_plog.as<double>(), c->plog_max_len, v);
+  HIPCHK(hipGetLastError());
   if (mem == NIMBLE_MEM_HOST) {
     HIPCHK(hipEventRecord(c->ev_used[k], c->stream));
     c->stage_busy[k] = true;
     c->stage_k ^= 1;
-  }
-  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
-  HIPCHK(hipGetLastError());
-  if (mem == NIMBLE_MEM_HOST) {
     if (lazy) c->h2d_pending[k] = true;                // waited for by the next append but one / the end of the stream
     else HIPCHK(hipEventSynchronize(c->ev_h2d[k]));  // the host buffers are free again
   }
   c->stream_n += m;
-  return NIMBLE_OK;
+  return stream_flush_align(c, false);
 }
 
 int nimble_stream_append_packed(nimble_ctx *c, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
@@ -1639,38 +1655,15 @@ int nimble_stream_append_packed(nimble_ctx *c, const uint64_t *r1_words, const u
   }
   HIPCHK(hipEventRecord(c->ev_h2d[k], c->h2d_stream));
   HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[k], 0));
-  CallBuffers v = c->cb;
-  const uint64_t B = c->stream_n;
-  v.n = m;
-  v.key_stride = c->stream_cap;
-  v.keys += B;
-  v.key_hash += B;
-  v.slot += B;
-  v.counted += B;
-  for (int mt = 0; mt < 2; ++mt) {
-    v.len[mt] += B;
-    v.alen[mt] += B;
-    v.pre[mt] += B;
-    v.reason[mt] += B;
-    v.score[mt] += B;
-    v.mism[mt] += B;
-    v.cls[mt] += B;
-    v.dyn_off[mt] += B;
-    v.dyn_len[mt] += B;
-    v.dyn_hash[mt] += B;
-    v.dyn_pos[mt] += B;
-  }
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
   launch_pack_words(c->stream, d_words[0], d_len[0], r1_stride, d_words[1], d_len[1], r2_stride, max_len,
-                    c->prm.min_read_length, c->b_plog.as<double>(), v);
+                    c->prm.min_read_length, c->b_plog.as<double>(), stream_view(c, c->stream_n, m));
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev_used[k], c->stream));
   c->stage_busy[k] = true;
   c->stage_k ^= 1;
-  launch_align(c->stream, c->ix->dev, c->prm, v, c->want_counters, c->align_grid_pct);
-  HIPCHK(hipGetLastError());
   c->h2d_pending[k] = true;
   c->stream_n += m;
-  return NIMBLE_OK;
+  return stream_flush_align(c, false);
 }
 
 int nimble_stream_end(nimble_ctx *c) {
@@ -1682,6 +1675,10 @@ int nimble_stream_end(nimble_ctx *c) {
       HIPCHK(hipEventSynchronize(c->ev_h2d[q]));
       c->h2d_pending[q] = false;
     }
+  {
+    const int frc = stream_flush_align(c, true);
+    if (frc) return frc;
+  }
   c->streaming = false;
   c->cb.n = c->stream_n;
   c->cb.key_stride = c->stream_cap;
