@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = the host CPUs this process is granted, at most 64)")
-    ap.add_argument("--e2e-reads", type=int, default=8_000_000,
+    ap.add_argument("--e2e-reads", type=int, default=16_000_000,
                     help="reads of the end-to-end FASTQ runs at N=1, plain and .gz (0 = skip)")
     args = ap.parse_args()
 
