@@ -19,6 +19,8 @@ HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box'
 (lib/nimble: parse, H2D, call, TSV) on a bounded file, outside the timed value.
 """
 import argparse
+
+import numpy as np
 import importlib
 import json
 import os
@@ -140,6 +142,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = the host CPUs this process is granted, at most 64)")
+    ap.add_argument("--packed-input", type=int, default=1,
+                    help="also time the steps with the reads handed over as 2-bit words (0 = skip); an extra key, not `value`")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000,
                     help="reads of the end-to-end FASTQ runs at N=1, plain and .gz (0 = skip)")
     args = ap.parse_args()
@@ -444,6 +448,55 @@ def main():
                 "parity_on_sample": "bit-exact table (%d rows)" % len(got),
             }
             out["speedup_vs_cpu_baseline"] = out["value"] / (per_unit * S / cpu_s)
+        # ---- the same steps with the reads handed over already packed (what score::call itself receives: DnaStrings,
+        # src/score.rs:14-31; the ASCII -> 2-bit conversion is the reader's, src/parse/fastq.rs:32): an extra figure, not
+        # `value`, which keeps the ASCII boundary of the earlier rounds
+        if args.packed_input and world == 1 and not paired and not sharded and depth > 1:
+            W = (L + 31) // 32
+            lut = torch.zeros(256, dtype=torch.int64, device=device)
+            for ch, code in ((b"C", 1), (b"G", 2), (b"T", 3), (b"c", 1), (b"g", 2), (b"t", 3)):
+                lut[ch[0]] = code
+            shifts = (62 - 2 * torch.arange(32, device=device, dtype=torch.int64))
+            wsets = []
+            for r1, _ in sets:
+                words = torch.zeros((n, W), dtype=torch.int64, device=device)
+                for lo in range(0, n, 1 << 20):
+                    hi = min(n, lo + (1 << 20))
+                    codes = torch.zeros((hi - lo, W * 32), dtype=torch.int64, device=device)
+                    codes[:, :L] = lut[r1[lo:hi].long()]
+                    words[lo:hi] = (codes.view(hi - lo, W, 32) << shifts).sum(dim=2)  # disjoint bit fields: the sum is their OR
+                    del codes
+                wsets.append(words)
+            lens = torch.full((n,), L, dtype=torch.int32, device=device)
+            torch.cuda.synchronize()
+
+            def begin_w(slot, k):
+                lib.score_call_begin_words(slot, wsets[k % n_sets], lens, W, n=n, max_len=L, mem=nim.MEM_DEVICE)
+
+            for s_ in range(2):
+                begin_w(s_, s_)
+            rows_w = None
+            for s_ in range(2):
+                rows_w = lib.score_call_end(s_, raw=True)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for i in range(args.steps):
+                begin_w(i % 2, i)
+                if i:
+                    rows_w = lib.score_call_end((i - 1) % 2, raw=True)
+            if args.steps:
+                rows_w = lib.score_call_end((args.steps - 1) % 2, raw=True)
+            torch.cuda.synchronize()
+            tw = time.perf_counter() - tw
+            if rows_w is not None and rows is not None and hasattr(rows, "signature") and (
+                    rows_w.signature() != rows.signature() or not np.array_equal(rows_w.counts(), rows.counts())):
+                raise SystemExit("bench.py: the table from packed input differs from the table from ASCII input")
+            out["packed_input"] = {
+                "reads_per_s": n * max(args.steps, 1) / tw, "ms_per_step": tw * 1000.0 / max(args.steps, 1),
+                "note": "the same %d steps with the reads handed over as 2-bit words (32 bases a u64, the layout of the "
+                        "reference's DnaString, which is what score::call receives): k_pack_words instead of k_pack; the "
+                        "table equals the ASCII run's" % args.steps}
+            del wsets
         # ---- end to end from a FASTQ file (SURVEY 8(d) figure B), outside the timed value
         if args.e2e_reads > 0 and world == 1 and not paired and not args.force_sharded:
             try:

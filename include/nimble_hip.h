@@ -151,6 +151,16 @@ int nimble_call(nimble_ctx *, const nimble_align_params *, const uint8_t *r1, co
                 const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len,
                 int mem);
 
+/* The call with the reads already packed -- the form score::call itself receives them in: its `sequences` are DnaStrings
+ * (src/score.rs:14-31; DnaString::from_acgt_bytes runs in the reader, src/parse/fastq.rs:32), 32 bases a u64.  Mate m of
+ * read i is r<m>_len[i] bases in the r<m>_stride words at r<m>_words + i * r<m>_stride, first base in the highest bit
+ * pair, A=0 C=1 G=2 T=3, zero bits behind the last base (layout and rules as nimble_stream_append_packed).  mem: host or
+ * device memory; as with nimble_call the buffers are borrowed until the first getter returns.  Results are those of
+ * nimble_call on the same reads. */
+int nimble_call_words(nimble_ctx *, const nimble_align_params *, const uint64_t *r1_words, const uint32_t *r1_len,
+                      uint32_t r1_stride, const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t n,
+                      uint32_t max_len, int mem);
+
 /* ---- the call as the BAM pipeline makes it (src/process/bam.rs:183-226,229-290; src/align.rs:516-552): many
  *      UMI groups in one launch, reads trimmed for quality before they are aligned, unpaired dummies skipped.
  *      Every field is optional (NULL / 0 = absent); the arrays live in the same memory space as the reads.

@@ -74,6 +74,10 @@ int nimble_score_call(nimble_library *, const uint8_t *r1, const uint64_t *r1_of
  * the host turns batch i's histogram into rows.  The read buffers of a slot are borrowed until its end. */
 int nimble_score_call_begin(nimble_library *, int slot, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                             const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem);
+/* the same with the reads already packed, as score::call receives them (DnaStrings): layout of nimble_call_words */
+int nimble_score_call_begin_words(nimble_library *, int slot, const uint64_t *r1_words, const uint32_t *r1_len,
+                                  uint32_t r1_stride, const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride,
+                                  uint64_t n, uint32_t max_len, int mem);
 int nimble_score_call_end(nimble_library *, int slot, nimble_rows **out);
 /* The BAM pipeline's calls (src/process/bam.rs:183-226,229-290): the reference runs score::call once per UMI
  * group with the reads' BAM metadata; here a whole batch of groups is ONE device call.  `extra` (all fields

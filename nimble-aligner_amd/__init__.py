@@ -87,7 +87,7 @@ HIP_SYMBOLS = [
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
     "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
-    "nimble_call_packed", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_append_packed", "nimble_stream_end",
+    "nimble_call_packed", "nimble_call_words", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_append_packed", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
@@ -133,6 +133,7 @@ def hip_lib():
         L.nimble_stream_begin.argtypes = [vp, C.POINTER(AlignParams), i32, u32, u64]
         L.nimble_stream_append.argtypes = [vp, vp, vp, vp, vp, u64, u32, i32]
         L.nimble_stream_append_packed.argtypes = [vp, vp, vp, u32, vp, vp, u32, u64]
+        L.nimble_call_words.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, u64, u32, i32]
         L.nimble_stream_end.argtypes = [vp]
         L.nimble_pinned_alloc.argtypes = [u64, C.POINTER(vp)]
         L.nimble_pinned_free.argtypes = [vp]
@@ -357,6 +358,15 @@ class Context:
                                               mem))
         self.n += n
 
+    def call_words(self, params, w1, len1, stride1, w2=None, len2=None, stride2=0, n=None, max_len=0, mem=MEM_HOST):
+        """nimble_call_words: the call on reads that are already packed."""
+        if n is None:
+            n = int(len(len1))
+        self._keep = (w1, len1, w2, len2)
+        _check(hip_lib().nimble_call_words(self.h, C.byref(params), _ptr(w1), _ptr(len1), stride1, _ptr(w2), _ptr(len2),
+                                           stride2, n, max(max_len, 1), mem))
+        self.n = n
+
     def stream_append_packed(self, w1, len1, stride1, w2=None, len2=None, stride2=0):
         """nimble_stream_append_packed: a batch the host has packed (pack_reads_2bit).  The arrays are kept alive here until
         the stream ends (the copy runs behind the call)."""
@@ -476,7 +486,7 @@ HOST_SYMBOLS = [
     "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
     "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
-    "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_end",
+    "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_begin_words", "nimble_score_call_end",
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
     "nimble_score_call_records_begin", "nimble_rows_signature", "nimble_rows_counts", "nimble_host_read_fastq_batched", "nimble_host_read_fastq_packed", "nimble_score_call_umis", "nimble_umi_rows_free",
     "nimble_umi_rows_count", "nimble_umi_rows_get", "nimble_umi_rows_reads", "nimble_umi_rows_filter", "nimble_score_stream_begin", "nimble_score_stream_append", "nimble_score_stream_end",
@@ -532,6 +542,7 @@ def host_lib():
         L.nimble_score_call.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(vp)]
         L.nimble_score_call_fastq.argtypes = [vp, cp, cp, C.POINTER(vp)]
         L.nimble_score_call_begin.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, u32, i32]
+        L.nimble_score_call_begin_words.argtypes = [vp, i32, vp, vp, u32, vp, vp, u32, u64, u32, i32]
         L.nimble_score_call_end.argtypes = [vp, i32, C.POINTER(vp)]
         L.nimble_library_ctx_slot.argtypes = [vp, i32]
         L.nimble_score_stream_begin.argtypes = [vp, i32, u32, u64]
@@ -853,6 +864,16 @@ class Library:
                 max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()))
         _hcheck(host_lib().nimble_score_call_begin(self.h, slot, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
                                                    fixed_len, max(max_len or fixed_len, 1), mem))
+
+    def score_call_begin_words(self, slot, w1, len1, stride1, w2=None, len2=None, stride2=0, n=None, max_len=0,
+                               mem=MEM_HOST):
+        """score_call_begin with the reads already packed (pack_reads_2bit / a device tensor of the same layout): the form
+        score::call itself receives its reads in.  The arrays must stay alive until score_call_end(slot)."""
+        if n is None:
+            n = int(len(len1))
+        self._keep_words = (w1, len1, w2, len2)
+        _hcheck(host_lib().nimble_score_call_begin_words(self.h, slot, _ptr(w1), _ptr(len1), stride1, _ptr(w2), _ptr(len2),
+                                                         stride2, n, max(max_len, 1), mem))
 
     def score_call_end(self, slot, raw=False):
         """Second half: wait for the slot's batch, return its sorted rows (a RowsHandle when raw)."""

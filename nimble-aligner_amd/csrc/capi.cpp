@@ -186,6 +186,10 @@ struct nimble_ctx {
   const uint8_t *in_r[2] = {nullptr, nullptr};
   const uint64_t *in_off[2] = {nullptr, nullptr};
   uint32_t in_fixed_len = 0, in_max_len = 0;
+  // nimble_call_words: the reads came packed (device pointers once staged); in_words[0] != nullptr selects k_pack_words
+  const uint64_t *in_words[2] = {nullptr, nullptr};
+  const uint32_t *in_len32[2] = {nullptr, nullptr};
+  uint32_t in_stride[2] = {0, 0};
   uint64_t dslots = 0;
   uint64_t dedup_clean_slots = 0;  // slots [0, this) of b_dedup are known to be zero (cleared at the tail of the last call)
   bool finished = true;
@@ -479,9 +483,14 @@ int enqueue_call(nimble_ctx *c) {
   CallBuffers &cb = c->cb;
   int rc = enqueue_head(c);
   if (rc) return rc;
-  if (!c->skip_pack)
-    launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
-                c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
+  if (!c->skip_pack) {
+    if (c->in_words[0])
+      launch_pack_words(s, c->in_words[0], c->in_len32[0], c->in_stride[0], c->in_words[1], c->in_len32[1], c->in_stride[1],
+                        c->in_max_len, c->prm.min_read_length, c->b_plog.as<double>(), cb);
+    else
+      launch_pack(s, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
+                  c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, cb);
+  }
   HIPCHK(hipEventRecord(c->ev[1], s));
   if (c->defer.active && !c->defer.routed) {
     rc = enqueue_route(c);
@@ -931,6 +940,7 @@ static int stage_inputs(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off
   c->in_off[1] = r2_off;
   c->in_fixed_len = fixed_len;
   c->in_max_len = max_len;
+  c->in_words[0] = c->in_words[1] = nullptr;
   if (mem != NIMBLE_MEM_HOST) return NIMBLE_OK;
   const int nm = r2 ? 2 : 1;
   for (int m = 0; m < nm; ++m) {
@@ -1128,6 +1138,60 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc) return rc;
   // classes are a function of the dedup key when the key fixes where R1 ends: single-end, or fixed-length mates
   c->cb.fuse_count = (!r2 || !r1_off) ? 1u : 0u;
+  c->skip_pack = false;
+  return start_call(c);
+}
+
+int nimble_call_words(nimble_ctx *c, const nimble_align_params *p, const uint64_t *r1_words, const uint32_t *r1_len,
+                      uint32_t r1_stride, const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t n,
+                      uint32_t max_len, int mem) {
+  if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call_words: NULL argument");
+  if (mem == NIMBLE_MEM_HOST_PINNED) mem = NIMBLE_MEM_HOST;
+  if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE) return fail(NIMBLE_E_INVALID, "nimble_call_words: bad mem");
+  const bool paired = r2_words != nullptr;
+  if ((r2_len != nullptr) != paired) return fail(NIMBLE_E_INVALID, "nimble_call_words: mate words and mate lengths go together");
+  if (n && (!r1_words || !r1_len || r1_stride == 0 || (paired && r2_stride == 0)))
+    return fail(NIMBLE_E_INVALID, "nimble_call_words: NULL buffer or zero stride");
+  if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_call_words: more than 2^32 reads in one call");
+  if (max_len == 0) max_len = 1;
+  if (max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call_words: max_len above 65535 is not supported");
+  HIPCHK(hipSetDevice(c->ix->device));
+  c->in_r[0] = c->in_r[1] = nullptr;
+  c->in_off[0] = c->in_off[1] = nullptr;
+  c->in_fixed_len = 0;
+  c->in_max_len = max_len;
+  const uint64_t *w[2] = {r1_words, r2_words};
+  const uint32_t *l[2] = {r1_len, r2_len};
+  const uint32_t st[2] = {r1_stride, r2_stride};
+  for (int m = 0; m < (paired ? 2 : 1); ++m) {
+    if (mem == NIMBLE_MEM_HOST) {
+      const uint64_t cap = std::min<uint64_t>(max_len, 32ULL * st[m]);
+      for (uint64_t i = 0; i < n; ++i)
+        if (l[m][i] > cap) return fail(NIMBLE_E_INVALID, "nimble_call_words: a read longer than max_len or than its words");
+      int rc = c->b_in[m].ensure(std::max<uint64_t>(n * st[m] * 8, 16), &c->bytes);
+      if (rc) return rc;
+      rc = c->b_in_off[m].ensure(std::max<uint64_t>(n * 4, 16), &c->bytes);
+      if (rc) return rc;
+      if (n) {
+        HIPCHK(hipMemcpyAsync(c->b_in[m].p, w[m], n * st[m] * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->b_in_off[m].p, l[m], n * 4, hipMemcpyHostToDevice, c->stream));
+      }
+      c->in_words[m] = c->b_in[m].as<uint64_t>();
+      c->in_len32[m] = c->b_in_off[m].as<uint32_t>();
+    } else {
+      c->in_words[m] = w[m];
+      c->in_len32[m] = l[m];
+    }
+    c->in_stride[m] = st[m];
+  }
+  if (!paired) {
+    c->in_words[1] = nullptr;
+    c->in_len32[1] = nullptr;
+    c->in_stride[1] = 0;
+  }
+  int rc = setup_call(c, p, n, paired, max_len, nullptr);
+  if (rc) return rc;
+  c->cb.fuse_count = paired ? 0u : 1u;  // (mates of varying length: where R1 ends is not fixed by the key)
   c->skip_pack = false;
   return start_call(c);
 }

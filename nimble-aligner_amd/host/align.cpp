@@ -495,6 +495,13 @@ void begin_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &i
   nimble_align_params p = make_params(config);
   uint32_t max_len = std::max(seqs.max_len, mates ? mates->max_len : 0u);
   if (max_len == 0) max_len = std::max(seqs.fixed_len, mates ? mates->fixed_len : 0u);
+  if (seqs.stride && (!mates || mates->stride)) {  // reads that are already packed (what score::call gets: DnaStrings)
+    check_rc(nimble_call_words(index.ctx(slot), &p, seqs.words, seqs.lens, seqs.stride, mates ? mates->words : nullptr,
+                               mates ? mates->lens : nullptr, mates ? mates->stride : 0u, seqs.n, max_len,
+                               seqs.device ? NIMBLE_MEM_DEVICE : NIMBLE_MEM_HOST),
+             "nimble_call_words");
+    return;
+  }
   // the device call is asynchronous: the coercion tables are (re)built while the GPU works
   check_rc(nimble_call(index.ctx(slot), &p, seqs.bases, seqs.offsets, mates ? mates->bases : nullptr,
                        mates ? mates->offsets : nullptr, seqs.n, seqs.fixed_len, max_len,

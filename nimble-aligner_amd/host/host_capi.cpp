@@ -197,6 +197,32 @@ int nimble_score_call_begin(nimble_library *l, int slot, const uint8_t *r1, cons
   });
 }
 
+int nimble_score_call_begin_words(nimble_library *l, int slot, const uint64_t *r1_words, const uint32_t *r1_len,
+                                  uint32_t r1_stride, const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride,
+                                  uint64_t n, uint32_t max_len, int mem) {
+  return guarded([&] {
+    if (!l->index) throw Panic("nimble_score_call_begin_words: the library has no index");
+    if (!call_slot(slot)) throw Panic("nimble_score_call_begin_words: slot must be 0, 1 or 3");
+    if (l->pending[slot]) throw Panic("nimble_score_call_begin_words: the slot already holds a call (end it first)");
+    if (!r1_words || !r1_len || r1_stride == 0 || ((r2_words != nullptr) != (r2_len != nullptr)) || (r2_words && r2_stride == 0))
+      throw Panic("nimble_score_call_begin_words: bad argument");
+    align::ReadBatch b1, b2;
+    b1.n = n;
+    b1.max_len = max_len;
+    b1.device = mem == NIMBLE_MEM_DEVICE;
+    b2 = b1;
+    b1.words = r1_words;
+    b1.lens = r1_len;
+    b1.stride = r1_stride;
+    b2.words = r2_words;
+    b2.lens = r2_len;
+    b2.stride = r2_stride;
+    align::begin_calls(b1, r2_words ? &b2 : nullptr, *l->index, l->cfg, slot);
+    l->pending[slot] = true;
+    l->pending_n[slot] = n;
+  });
+}
+
 int nimble_score_call_end(nimble_library *l, int slot, nimble_rows **out) {
   *out = nullptr;
   return guarded([&] {

@@ -478,6 +478,54 @@ def test_stream_append_packed_equals_ascii_append(synth_lib, paired):
         ctx.stream_end()
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_call_words_equals_call(synth_lib, paired):
+    # nimble_call_words / nimble_score_call_begin_words (reads handed over as DnaString-style words, host and device
+    # memory) against nimble_call on the same reads: per-read records, histogram, rows
+    torch = pytest.importorskip("torch")
+    path, seqs = synth_lib
+    n = 20_000
+    rng = np.random.default_rng(5)
+    def ragged(reads, seed):
+        r = np.random.default_rng(seed)
+        lens = r.integers(25, 151, size=n)
+        return [bytes(reads[i, :lens[i]]) for i in range(n)]
+    s1 = ragged(synth.make_reads(seqs, n, seed=611), 1)
+    s2 = ragged(synth.make_reads(seqs, n, seed=612), 2) if paired else None
+    lib = nim.Library(path, "unstranded").build_index()
+    ctx = lib.device_context()
+    f1, o1 = nim.pack_reads(s1)
+    f2, o2 = nim.pack_reads(s2) if paired else (None, None)
+    want_rows = lib.score_call(f1, o1, f2, o2)
+    ctx.n = n
+    want = [ctx.read_records(m) for m in range(2 if paired else 1)], ctx.histogram()
+    w1, l1, st1 = nim.pack_reads_2bit(s1)
+    w2, l2, st2 = nim.pack_reads_2bit(s2, 6) if paired else (None, None, 0)
+    for mem in ("host", "device"):
+        if mem == "device":
+            a1, b1 = torch.from_numpy(w1.view(np.int64)).to("cuda:0"), torch.from_numpy(l1.view(np.int32)).to("cuda:0")
+            a2 = b2 = None
+            if paired:
+                a2, b2 = torch.from_numpy(w2.view(np.int64)).to("cuda:0"), torch.from_numpy(l2.view(np.int32)).to("cuda:0")
+            torch.cuda.synchronize()
+            lib.score_call_begin_words(0, a1, b1, st1, a2, b2, st2, n=n, max_len=150, mem=nim.MEM_DEVICE)
+        else:
+            lib.score_call_begin_words(0, w1, l1, st1, w2, l2, st2, n=n, max_len=150)
+        assert lib.score_call_end(0) == want_rows, mem
+        ctx.n = n
+        for m in range(2 if paired else 1):
+            rec = ctx.read_records(m)
+            for key in ("reason", "score", "mismatches", "cls", "counted"):
+                np.testing.assert_array_equal(rec[key], want[0][m][key], err_msg="%s %s mate %d" % (mem, key, m))
+        assert ctx.histogram() == want[1]
+    # the device entry on its own, and its argument checks
+    p = lib.align_params()
+    ctx.call_words(p, w1, l1, st1, w2, l2, st2, max_len=150)
+    assert ctx.histogram() == want[1]
+    with pytest.raises(nim.NimbleError, match="longer than"):
+        ctx.call_words(p, w1, np.full(n, 999, dtype=np.uint32), st1, w2, l2, st2, max_len=150)
+
+
 @pytest.mark.parametrize("batch", ["0", "300"])
 def test_fastq_pull_order_and_blank_quality_line(synth_lib, tmp_path, monkeypatch, batch):
     # The reference pulls R1 record i, then R2 record i (align.rs:511-541), so (a) R2 is never read beyond R1's last
