@@ -19,8 +19,6 @@ HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box'
 (lib/nimble: parse, H2D, call, TSV) on a bounded file, outside the timed value.
 """
 import argparse
-
-import numpy as np
 import importlib
 import json
 import os
@@ -29,6 +27,8 @@ import subprocess
 import sys
 import tempfile
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
