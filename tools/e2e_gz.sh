@@ -41,10 +41,11 @@ wantq = run("plain, %d reads" % (N // 4), d + "/q.fastq", N // 4, {})
 assert run("gzip -6 (gzip itself), one thread (zlib)", d + "/q6.fastq.gz", N // 4, {"NIMBLE_GZIP_SERIAL": "1"}, reps=1) == wantq
 assert run("gzip -6 (gzip itself), defaults", d + "/q6.fastq.gz", N // 4, {"NIMBLE_GZIP_DEBUG": "1"}, show=True) == wantq
 p = d + "/r6.fastq.gz"
-for t in (16, 32, 64):
-    assert run("one member, %d decoder threads" % t, p, N, {"NIMBLE_GZIP_THREADS": str(t)}) == want
 assert run("one member, defaults", p, N, {"NIMBLE_GZIP_DEBUG": "1"}, show=True) == want
-assert run("one member, defaults, 128 MiB windows", p, N, {"NIMBLE_GZIP_WINDOW": str(128 << 20)}) == want
-assert run("one member, defaults, 8 MiB chunks", p, N, {"NIMBLE_GZIP_CHUNK": str(8 << 20)}) == want
+for pt in (2, 4, 8):
+    assert run("one member, %d parser threads" % pt, p, N, {"NIMBLE_FASTQ_THREADS": str(pt)}) == want
+for gt, pt in ((14, 4), (12, 4), (16, 4), (20, 4)):
+    assert run("one member, %d decoder + %d parser threads" % (gt, pt), p, N, {"NIMBLE_GZIP_THREADS": str(gt), "NIMBLE_FASTQ_THREADS": str(pt)}) == want
+assert run("one member, 128 MiB windows, 4 parser threads", p, N, {"NIMBLE_GZIP_WINDOW": str(128 << 20), "NIMBLE_FASTQ_THREADS": "4"}) == want
 subprocess.run(["rm", "-rf", d])
 PY
