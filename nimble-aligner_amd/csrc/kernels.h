@@ -86,7 +86,7 @@ struct CallBuffers {
   uint64_t hist_mask;
   // [0..7] = counters of nimble_call_counters, [8]=scratch used [9]=unresolved interns
   // [10]=error flags [11]=histogram entries (compaction) [12]=align tile counter
-  // [13]=free [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len;
+  // [13]=third and later copies of a key met by the dedup sample [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len;
   // cleared by the host) [15]=duplicates met by the dedup sample
   uint64_t *state;
 };

@@ -1494,8 +1494,17 @@ __device__ __forceinline__ void dedup_one(const nimble_align_params &p, const Ca
       if (cb.seg) diff |= (uint64_t)(cb.seg[j] ^ seg);
       for (uint32_t w = 0; w < nw; ++w) diff |= rd_key(cb, w, i) ^ rd_key(cb, w, j);
       if (diff == 0) {
-        if (mode != 0 && !look) cb.hot[hot_slot] = h;
-        if (mode == 1) atomicAdd((unsigned long long *)&cb.state[15], 1ULL);
+        if (mode == 1) {
+          // the sample: a second copy marks the key in the set; a copy that finds it marked already is a third or later
+          // one, and state[13] counts those -- what tells a key with MANY copies, which the main launch has to be
+          // careful with, from an input that merely holds pairs of equal reads (5 % of the bench reads are such pairs:
+          // taken for dominant keys they cost the main launch 5 % for nothing)
+          const unsigned long long was = atomicExch((unsigned long long *)&cb.hot[hot_slot], (unsigned long long)h);
+          if (was == h) atomicAdd((unsigned long long *)&cb.state[13], 1ULL);
+          atomicAdd((unsigned long long *)&cb.state[15], 1ULL);
+        } else if (mode != 0 && !look) {
+          cb.hot[hot_slot] = h;
+        }
         if (j < i) atomicMax((unsigned long long *)&cb.dedup[pos], (unsigned long long)mine);
         else if (look && he && nw <= HC_WORDS && atomicCAS((uint32_t *)&he->state, 0u, 1u) == 0u) {
           he->h = h;
@@ -1521,10 +1530,11 @@ __global__ __launch_bounds__(256) void k_dedup(nimble_align_params p, CallBuffer
   for (uint32_t e = threadIdx.x; e < HC_ENTRIES; e += blockDim.x) s_hot[e].state = 0u;
   __syncthreads();
   const uint64_t n = cb.n;
-  // The sample launch (the last reads, g_begin == 0 of a split launch) counts the duplicates it meets; only when it
-  // met some does the main launch pay for the look-before-atomic machinery.
+  // The sample launch (the last reads, g_begin == 0 of a split launch) counts the duplicates it meets (state[15]) and,
+  // apart, the third and later copies of a key (state[13]); only when it met some of THOSE does the main launch pay for
+  // the look-before-atomic machinery.
   const bool is_sample = cb.hot && g_begin == 0 && g_end < n;
-  const int mode = !cb.hot ? 0 : is_sample ? 1 : (g_begin != 0 && cb.state[15] >= 4 ? 2 : 0);
+  const int mode = !cb.hot ? 0 : is_sample ? 1 : (g_begin != 0 && cb.state[13] >= 4 ? 2 : 0);
   HotEntry *hc = mode == 2 ? s_hot : nullptr;
   // per-block callset counters: plain calls only (a representative read per entry, BAM mode, needs the global max)
   __shared__ HotCls s_cls[HCLS_ENTRIES];
