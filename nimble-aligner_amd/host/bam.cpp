@@ -19,6 +19,11 @@
 //     an error, and UMIReader takes any error for the end of the file (sorted_bam_reader.rs:169-186, parse/bam.rs:113-117).
 // The reference's rows leave its consumer pool in no fixed order; here they are written in UMI order, callsets sorted (the
 // order of score::call), then the pairs without a call.
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <chrono>
 #include <zlib.h>
 
 #include <algorithm>
@@ -170,6 +175,60 @@ bool Record::aux_string(const char *tag, std::string &out) const {
 }
 
 // rust-htslib Record::read_pair_orientation
+// The fifteen two-character tags of BAM_FIELDS_TO_REPORT in ONE walk over the aux data, each with the answer aux_string
+// would give (the first entry of a tag decides: a string gives its value, any other type gives nothing, and nothing behind
+// a malformed entry is seen).  have[k] = tag k is a string; out[k] its value.
+static const char *const REPORT_TAGS[15] = {"NH", "HI", "AS", "GN", "TX", "AN", "nM", "fx", "RE", "CR", "CY", "CB", "UR", "UY", "UB"};
+static void aux_report_tags(const Record &r, std::string *out, bool *have) {
+  bool seen[15];
+  for (int k = 0; k < 15; ++k) seen[k] = have[k] = false;
+  const std::vector<uint8_t> &aux = r.aux;
+  size_t o = 0;
+  const size_t n = aux.size();
+  while (o + 3 <= n) {
+    const char t0 = (char)aux[o], t1 = (char)aux[o + 1], ty = (char)aux[o + 2];
+    o += 3;
+    int k = -1;
+    for (int q = 0; q < 15; ++q)
+      if (REPORT_TAGS[q][0] == t0 && REPORT_TAGS[q][1] == t1) {
+        k = q;
+        break;
+      }
+    size_t len = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': len = 1; break;
+      case 's': case 'S': len = 2; break;
+      case 'i': case 'I': case 'f': len = 4; break;
+      case 'Z': case 'H': {
+        size_t e = o;
+        while (e < n && aux[e] != 0) ++e;
+        if (e >= n) return;
+        if (k >= 0 && !seen[k]) {
+          seen[k] = true;
+          if (ty == 'Z') {
+            have[k] = true;
+            out[k].assign(reinterpret_cast<const char *>(aux.data() + o), e - o);
+          }
+        }
+        o = e + 1;
+        continue;
+      }
+      case 'B': {
+        if (o + 5 > n) return;
+        const char sub = (char)aux[o];
+        uint32_t cnt;
+        memcpy(&cnt, aux.data() + o + 1, 4);
+        const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        len = 5 + w * (size_t)cnt;
+        break;
+      }
+      default: return;
+    }
+    if (k >= 0) seen[k] = true;  // present, but not a string
+    o += len;
+  }
+}
+
 static const char *pair_orientation(const Record &r) {
   const bool paired = r.flag & 0x1, unmapped = r.flag & 0x4, mate_unmapped = r.flag & 0x8;
   if (!(paired && !unmapped && !mate_unmapped && r.tid == r.mtid)) return "None";
@@ -209,15 +268,14 @@ void SortedBamReader::fill_buffer() {
     if (current_umi_.empty()) current_umi_ = umi;
     if (current_umi_ != umi) {
       // records of one UMI ordered by cell barcode (a stable sort, like Vec::sort_by)
-      std::stable_sort(buffer_.begin(), buffer_.end(), [](const Record &a, const Record &b) {
-        std::string ca, cb2;
-        if (!a.aux_string("CB", ca) || !b.aux_string("CB", cb2)) throw Panic("Could not read CB");
-        return ca < cb2;
-      });
+      // (the barcode every buffered record was checked to have, read once when it came in)
+      std::stable_sort(buffer_.begin(), buffer_.end(), [](const Record &a, const Record &b) { return a.cb < b.cb; });
+      rec.cb = std::move(cb);
       next_records_.push_back(std::move(rec));
       next_umi_ = umi;
       return;
     }
+    rec.cb = std::move(cb);
     buffer_.push_back(std::move(rec));
     rec = Record();
   }
@@ -225,14 +283,16 @@ void SortedBamReader::fill_buffer() {
 
 void SortedBamReader::add_dummy_paired_reads() {
   std::vector<Record> out;
-  for (const Record &r : buffer_) {
-    Record real = r;
-    real.skip_align = "FALSE";
-    out.push_back(std::move(real));
+  out.reserve(buffer_.size());
+  for (Record &r : buffer_) {
+    r.skip_align = "FALSE";
     if (!(r.flag & 0x1)) {
       Record dummy = r;
       dummy.skip_align = "TRUE";
+      out.push_back(std::move(r));
       out.push_back(std::move(dummy));
+    } else {
+      out.push_back(std::move(r));
     }
   }
   buffer_.swap(out);
@@ -245,14 +305,14 @@ void SortedBamReader::filter_paired_reads() {
   while (i < buffer_.size()) {
     if (i + 1 >= buffer_.size()) break;
     if (buffer_[i].qname == buffer_[i + 1].qname) {
-      if (buffer_[i].flag & 0x40) {
-        out.push_back(buffer_[i]);
-        out.push_back(buffer_[i + 1]);
-      } else {
-        out.push_back(buffer_[i + 1]);
-        out.push_back(buffer_[i]);
-      }
       seen.insert(buffer_[i].qname);
+      if (buffer_[i].flag & 0x40) {
+        out.push_back(std::move(buffer_[i]));
+        out.push_back(std::move(buffer_[i + 1]));
+      } else {
+        out.push_back(std::move(buffer_[i + 1]));
+        out.push_back(std::move(buffer_[i]));
+      }
       i += 2;
     } else {
       puts("Warning: Unpaired qname!");
@@ -325,9 +385,15 @@ bool UMIReader::get_umi_from_bam() {
     if (!reader_.next(record)) return false;
     ++read_counter_;
     if (read_counter_ % 1000000 == 0) printf("Aligned reads %zu-%zu\n", read_counter_ - 1000000, read_counter_);
-    const std::string read_umi = umi_of(record);
-    std::string cb;
-    if (!record.aux_string("CB", cb)) throw Panic("Error Read without cell barcode, cannot excise read-mate.");
+    // (one walk over the aux data for the fifteen reported tags, the UMI and the cell barcode; the 38 fields by position
+    // in BAM_FIELDS_TO_REPORT -- a lookup by name per field and record was most of the pipeline's time)
+    std::string tagv[15];
+    bool tagh[15];
+    aux_report_tags(record, tagv, tagh);
+    if (!tagh[14] && !tagh[12]) throw Panic("Error -- Could not read UMI.");
+    const std::string read_umi = tagh[14] ? tagv[14] : tagv[12];  // corrected UB, else raw UR
+    if (!tagh[11]) throw Panic("Error Read without cell barcode, cannot excise read-mate.");
+    const std::string &cb = tagv[11];
     const std::string cell = cb.size() >= 2 ? cb.substr(0, cb.size() - 2) : std::string();
     const std::string key = read_umi + cell;
     if (current_umi.empty()) current_umi = read_umi;
@@ -340,38 +406,33 @@ bool UMIReader::get_umi_from_bam() {
       qual.clear();
     }
     qual = strip_nonbio_regions_qual(qual, rev);
-    std::vector<std::string> fields;
-    fields.reserve(38);
+    std::vector<std::string> fields(38);
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    for (const char *field : BAM_FIELDS_TO_REPORT) {
-      std::string v;
-      const std::string f = field;
-      if (f == "SKIP_ALIGN") v = record.skip_align;
-      else if (record.aux_string(field, v)) { /* a string tag of that name */ }
-      else if (f == "QNAME") v = record.qname;
-      else if (f == "QUAL") v = qual;
-      else if (f == "REVERSE") v = b(rev);
-      else if (f == "MATE_REVERSE") v = b(record.flag & 0x20);
-      else if (f == "PAIRED") v = b(record.flag & 0x1);
-      else if (f == "PROPER_PAIRED") v = b(record.flag & 0x2);
-      else if (f == "PAIR_ORIENTATION") v = pair_orientation(record);
-      else if (f == "UNMAPPED") v = b(record.flag & 0x4);
-      else if (f == "MATE_UNMAPPED") v = b(record.flag & 0x8);
-      else if (f == "FIRST_IN_TEMPLATE") v = b(record.flag & 0x40);
-      else if (f == "LAST_IN_TEMPLATE") v = b(record.flag & 0x80);
-      else if (f == "STRAND") v = rev ? "-" : "+";
-      else if (f == "MAPQ") v = std::to_string(record.mapq);
-      else if (f == "POS") v = std::to_string((long long)record.pos);
-      else if (f == "MATE_POS") v = std::to_string((long long)record.mpos);
-      else if (f == "SEQ") v = seq;
-      else if (f == "SEQ_LEN") v = std::to_string(record.seq.size());
-      else if (f == "INSERT_SIZE") v = std::to_string((long long)record.tlen);
-      else if (f == "QUALITY_FAILED") v = b(record.flag & 0x200);
-      else if (f == "SECONDARY") v = b(record.flag & 0x100);
-      else if (f == "DUPLICATE") v = b(record.flag & 0x400);
-      else if (f == "SUPPLEMENTARY") v = b(record.flag & 0x800);
-      fields.push_back(std::move(v));
-    }
+    fields[0] = record.qname;
+    fields[1] = std::move(qual);
+    fields[2] = b(rev);
+    fields[3] = b(record.flag & 0x20);
+    fields[4] = b(record.flag & 0x1);
+    fields[5] = b(record.flag & 0x2);
+    fields[6] = pair_orientation(record);
+    fields[7] = b(record.flag & 0x4);
+    fields[8] = b(record.flag & 0x8);
+    fields[9] = b(record.flag & 0x40);
+    fields[10] = b(record.flag & 0x80);
+    fields[11] = rev ? "-" : "+";
+    fields[12] = std::to_string(record.mapq);
+    fields[13] = std::to_string((long long)record.pos);
+    fields[14] = std::to_string((long long)record.mpos);
+    fields[15] = seq;
+    fields[16] = std::to_string(record.seq.size());
+    fields[17] = std::to_string((long long)record.tlen);
+    fields[18] = b(record.flag & 0x200);
+    fields[19] = b(record.flag & 0x100);
+    fields[20] = b(record.flag & 0x400);
+    fields[21] = b(record.flag & 0x800);
+    for (int k = 0; k < 15; ++k)
+      if (tagh[k]) fields[22 + k] = std::move(tagv[k]);  // (tagv[11..14] are not used again below)
+    fields[37] = record.skip_align;
     if (current_iteration_key_ == key) {
       current_umi_group.push_back(seq);
       current_metadata_group.push_back(std::move(fields));
@@ -433,6 +494,117 @@ std::string bam_header(const char *prefix) {
   return s;
 }
 
+// The output file as ONE gzip member (what flate2's GzEncoder writes, process/bam.rs:60-75) deflated by several threads the way
+// pigz does it: the text is cut into blocks, each block is deflated raw and closed with a sync flush (the last with a
+// finish), the blocks are written in order, and the member's CRC-32 is combined from the blocks'.  One zlib stream at
+// level 6 wrote 60 MB of this very repetitive text per second and was the slowest stage of the pipeline.
+class GzWriter {
+ public:
+  GzWriter(const std::string &path, unsigned threads) {
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) throw Panic("could not create " + path);
+    static const unsigned char head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+    fwrite(head, 1, 10, f_);
+    for (unsigned t = 0; t < std::max(1u, threads); ++t) workers_.emplace_back([this] { work(); });
+  }
+  void write(const char *p, size_t n) {
+    cur_.append(p, n);
+    if (cur_.size() >= BLOCK) submit(false);
+  }
+  bool close() {  // true = everything written
+    submit(true);
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return written_ == jobs_.size(); });
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &w : workers_) w.join();
+    workers_.clear();
+    unsigned char tail[8];
+    for (int k = 0; k < 4; ++k) {
+      tail[k] = (unsigned char)(crc_ >> (8 * k));
+      tail[4 + k] = (unsigned char)((uint32_t)total_ >> (8 * k));
+    }
+    bool ok = !failed_ && fwrite(tail, 1, 8, f_) == 8;
+    ok = fclose(f_) == 0 && ok;
+    f_ = nullptr;
+    return ok;
+  }
+  ~GzWriter() {
+    if (f_) (void)close();
+  }
+
+ private:
+  static constexpr size_t BLOCK = 1u << 20;
+  struct Job {
+    std::string text, out;
+    uint32_t crc = 0;
+    bool last = false, done = false;
+  };
+  void submit(bool last) {
+    std::unique_ptr<Job> j(new Job());
+    j->text.swap(cur_);
+    j->last = last;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return jobs_.size() - written_ < 4 * workers_.size() + 4; });  // bounded memory
+    jobs_.push_back(std::move(j));
+    lk.unlock();
+    cv_.notify_all();
+  }
+  void work() {
+    for (;;) {
+      Job *j = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || next_ < jobs_.size(); });
+        if (next_ >= jobs_.size()) return;
+        j = jobs_[next_++].get();
+      }
+      z_stream z;
+      memset(&z, 0, sizeof z);
+      bool ok = deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+      if (ok) {
+        j->out.resize(deflateBound(&z, (uLong)j->text.size()) + 16);
+        z.next_in = (Bytef *)j->text.data();
+        z.avail_in = (uInt)j->text.size();
+        z.next_out = (Bytef *)&j->out[0];
+        z.avail_out = (uInt)j->out.size();
+        const int rc = deflate(&z, j->last ? Z_FINISH : Z_SYNC_FLUSH);
+        ok = j->last ? rc == Z_STREAM_END : (rc == Z_OK && z.avail_in == 0);
+        j->out.resize(j->out.size() - z.avail_out);
+        deflateEnd(&z);
+      }
+      j->crc = (uint32_t)crc32(0, (const Bytef *)j->text.data(), (uInt)j->text.size());
+      std::unique_lock<std::mutex> lk(mu_);
+      if (!ok) failed_ = true;
+      j->done = true;
+      // whoever completes the next block in file order writes it and the finished ones behind it
+      while (written_ < jobs_.size() && jobs_[written_]->done) {
+        Job &w = *jobs_[written_];
+        if (fwrite(w.out.data(), 1, w.out.size(), f_) != w.out.size()) failed_ = true;
+        crc_ = (uint32_t)crc32_combine(crc_, w.crc, (z_off_t)w.text.size());
+        total_ += w.text.size();
+        w.text = std::string();
+        w.out = std::string();
+        ++written_;
+      }
+      lk.unlock();
+      cv_.notify_all();
+    }
+  }
+  FILE *f_ = nullptr;
+  std::string cur_;
+  std::vector<std::unique_ptr<Job>> jobs_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  size_t next_ = 0, written_ = 0;
+  uint64_t total_ = 0;
+  uint32_t crc_ = 0;
+  bool stop_ = false, failed_ = false;
+};
+
 struct Group {  // one UMI x cell barcode: records 2k / 2k + 1 are a pair
   std::vector<std::string> seqs;
   std::vector<std::vector<std::string>> meta;
@@ -447,12 +619,11 @@ void process(const std::vector<std::string> &input_files,
              size_t num_cores, bool force_bam_paired) {
   (void)num_cores;  // the reference's consumer pool: here the UMI groups of a batch share one device call
   const size_t n_lib = reference_indices.size();
-  std::vector<gzFile> out(n_lib, nullptr);
+  std::vector<std::unique_ptr<GzWriter>> out(n_lib);
   puts("Spawning logging thread.");
-  for (size_t i = 0; i < n_lib; ++i) {
-    out[i] = gzopen(output_paths.at(i).c_str(), "wb6");  // created / truncated; flate2 Compression::default() = 6
-    if (!out[i]) throw Panic("could not create " + output_paths[i]);
-  }
+  const unsigned gz_threads = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
+  for (size_t i = 0; i < n_lib; ++i)  // created / truncated; level 6 = flate2 Compression::default()
+    out[i].reset(new GzWriter(output_paths.at(i), gz_threads));
   std::vector<bool> first_write(n_lib, true);
   auto write_line = [&](size_t lib, const std::string &line) {
     if (first_write[lib]) {
@@ -460,20 +631,22 @@ void process(const std::vector<std::string> &input_files,
       const std::string h = "nimble_features\tnimble_score\t" + bam_header("r1") + "\t" + bam_header("r2") +
                             "\tr1_filter_forward\tr1_forward_score\tr1_filter_reverse\tr1_reverse_score\tr2_filter_forward"
                             "\tr2_forward_score\tr2_filter_reverse\tr2_reverse_score\ttriage_reason\taligndirection\n";
-      gzwrite(out[lib], h.data(), (unsigned)h.size());
+      out[lib]->write(h.data(), h.size());
       first_write[lib] = false;
     }
-    gzwrite(out[lib], line.data(), (unsigned)line.size());
+    out[lib]->write(line.data(), line.size());
   };
 
   // UMI groups are gathered into batches: one device call per batch and library, the group index is the segment
-  size_t batch_pairs = 1u << 20;
+  size_t batch_pairs = 1u << 17;  // (small enough that the reader thread and the consumer overlap on ordinary files)
   if (const char *e = getenv("NIMBLE_BAM_BATCH")) batch_pairs = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1);
   std::vector<Group> groups;
   size_t pairs = 0;
 
+  double t_prep = 0, t_call = 0, t_rows = 0;
   auto flush = [&]() {
     if (groups.empty()) return;
+    const auto tp0 = std::chrono::steady_clock::now();
     // the call's inputs: R1 = record 2k, R2 = record 2k + 1, each reverse-complemented when the BAM says the read was
     // (process/bam.rs:245-303); the quality strings are already in read direction (parse/bam.rs:270-287)
     std::vector<uint8_t> b[2], q[2], skip[2];
@@ -519,8 +692,17 @@ void process(const std::vector<std::string> &input_files,
       ex.qual[1] = q[1].data();
       ex.skip[0] = skip[0].data();
       ex.skip[1] = skip[1].data();
+      const auto tc0 = std::chrono::steady_clock::now();
+      if (lib == 0) t_prep += std::chrono::duration<double>(tc0 - tp0).count();
       align::UmiOutput res = align::get_calls_umis(a, &m, ex, *reference_indices[lib], references.at(lib),
                                                    aligner_configs.at(lib), true);
+      const auto tr0 = std::chrono::steady_clock::now();
+      t_call += std::chrono::duration<double>(tr0 - tc0).count();
+      struct RowsLap {
+        double &acc;
+        std::chrono::steady_clock::time_point t0;
+        ~RowsLap() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+      } rows_lap{t_rows, tr0};
       size_t row = 0;
       for (size_t g = 0; g < groups.size(); ++g) {
         const Group &G = groups[g];
@@ -567,26 +749,97 @@ void process(const std::vector<std::string> &input_files,
     pairs = 0;
   };
 
+  // The reader runs on a thread of its own, one batch ahead (the reference has a reader thread and a pool of consumers,
+  // process/bam.rs:127-226): BGZF, record decoding and the 38 strings per record are the pipeline's largest cost and
+  // overlap the device call and the writing of the batch before.
   puts("Spawning reader thread.");
-  parse::bam::UMIReader reader(input_files.at(0), false, force_bam_paired);
-  bool has_aligned = false;
-  for (;;) {
-    const bool final_umi = reader.next();
-    if (final_umi && has_aligned) {
-      puts("Finished reading UMIs from input file.");
-      break;
+  struct Batch {
+    std::vector<Group> groups;
+    std::string error;
+    bool last = false;
+  };
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::deque<std::unique_ptr<Batch>> queue;
+  bool quit = false;
+  double t_read = 0;
+  std::thread reader_thread([&] {
+    std::unique_ptr<Batch> cur(new Batch());
+    size_t cur_pairs = 0;
+    auto push = [&](bool last) {
+      cur->last = last;
+      std::unique_lock<std::mutex> lk(qmu);
+      qcv.wait(lk, [&] { return quit || queue.size() < 2; });
+      if (quit) return false;
+      queue.push_back(std::move(cur));
+      lk.unlock();
+      qcv.notify_all();
+      cur.reset(new Batch());
+      cur_pairs = 0;
+      return true;
+    };
+    try {
+      const auto t0 = std::chrono::steady_clock::now();
+      parse::bam::UMIReader reader(input_files.at(0), false, force_bam_paired);
+      bool has_aligned = false;
+      for (;;) {
+        const bool final_umi = reader.next();
+        if (final_umi && has_aligned) {
+          puts("Finished reading UMIs from input file.");
+          break;
+        }
+        Group g;
+        g.seqs = std::move(reader.current_umi_group);
+        g.meta = std::move(reader.current_metadata_group);
+        cur_pairs += g.seqs.size() / 2;
+        cur->groups.push_back(std::move(g));
+        if (cur_pairs >= batch_pairs && !push(false)) return;
+        has_aligned = true;
+      }
+      t_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } catch (const std::exception &e) {
+      cur->error = e.what();
     }
-    Group g;
-    g.seqs = reader.current_umi_group;
-    g.meta = reader.current_metadata_group;
-    pairs += g.seqs.size() / 2;
-    groups.push_back(std::move(g));
-    if (pairs >= batch_pairs) flush();
-    has_aligned = true;
+    (void)push(true);
+  });
+  double t_wait = 0, t_flush = 0;
+  std::string failure;
+  try {
+    for (;;) {
+      std::unique_ptr<Batch> bt;
+      const auto tw = std::chrono::steady_clock::now();
+      {
+        std::unique_lock<std::mutex> lk(qmu);
+        qcv.wait(lk, [&] { return !queue.empty(); });
+        bt = std::move(queue.front());
+        queue.pop_front();
+      }
+      qcv.notify_all();
+      const auto tf = std::chrono::steady_clock::now();
+      t_wait += std::chrono::duration<double>(tf - tw).count();
+      groups = std::move(bt->groups);
+      flush();
+      t_flush += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
+      if (!bt->error.empty()) failure = bt->error;
+      if (bt->last) break;
+    }
+  } catch (...) {
+    {
+      std::lock_guard<std::mutex> lk(qmu);
+      quit = true;
+    }
+    qcv.notify_all();
+    reader_thread.join();
+    throw;
   }
-  flush();
+  reader_thread.join();
+  if (!failure.empty()) throw Panic(failure);
+  if (getenv("NIMBLE_HOST_TIMING"))
+    fprintf(stderr, "[nimble host] bam pipeline: reader thread %.2f s (BGZF, records, UMI groups); consumer %.2f s waiting for it, "
+            "%.2f s in calls and rows (%.2f preparing the calls' inputs, %.2f in the calls, %.2f writing rows)\n", t_read, t_wait,
+            t_flush, t_prep, t_call, t_rows);
   for (size_t i = 0; i < n_lib; ++i) {
-    if (gzclose(out[i]) == Z_OK) printf("Successfully flushed and closed file %zu\n", i);
+    if (out[i]->close()) printf("Successfully flushed and closed file %zu\n", i);
     else fprintf(stderr, "Error finishing GZIP for file %zu\n", i);
   }
   for (const std::string &p : output_paths) {  // validate_gzip (process/bam.rs:425-435)

@@ -460,6 +460,7 @@ struct Record {
   std::string qname, seq /* ASCII, "=ACMGRSVTWYHKDBN" */, qual /* raw Phred bytes */;
   std::vector<uint8_t> aux;
   std::string skip_align;  // the SKIP_ALIGN tag SortedBamReader pushes ("TRUE" / "FALSE"; empty = not pushed)
+  std::string cb;          // the CB tag, kept by SortedBamReader for its sort (not a BAM field)
   bool aux_string(const char *tag, std::string &out) const;  // Aux::String (type Z) only
 };
 extern const char *const BAM_FIELDS_TO_REPORT[38];  // src/parse/bam.rs:9-49

@@ -1,0 +1,104 @@
+"""End-to-end rate of the BAM pipeline (development aid): lib/nimble on a synthetic 10x-style BAM.
+python tools/e2e_bam.py [pairs] [pairs per UMI]
+The BAM is written here, vectorised (fixed-length proper pairs, mates adjacent, runs of one UMI, CB / UB / UR tags, BGZF
+blocks deflated by a process pool); reads come from the bench's generator so that most of them align."""
+import importlib, os, struct, subprocess, sys, tempfile, time, zlib
+import multiprocessing as mp
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+synth = importlib.import_module("nimble-aligner_amd.synth")
+
+
+def _block(data):
+    comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = comp.compress(data) + comp.flush()
+    head = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, 12 + 6 + len(body) + 8 - 1)
+    return head + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def write_bam(path, r1, r2, per_umi, rng):
+    n, L = r1.shape
+    code = np.zeros(256, dtype=np.uint8)
+    for c, v in zip(b"=ACMGRSVTWYHKDBN", range(16)):
+        code[c] = v
+    name_len = 12  # "q%010d\0"
+    aux = 3 + 19 + 3 + 11 + 3 + 11  # CB:Z:<16>-1\0  UB:Z:<10>\0  UR:Z:<10>\0
+    body_len = 32 + name_len + (L + 1) // 2 + L + aux
+    rec = np.zeros((2 * n, 4 + body_len), dtype=np.uint8)
+    rec[:, 0:4] = np.frombuffer(struct.pack("<i", body_len), dtype=np.uint8)
+    fixed = np.frombuffer(struct.pack("<iiBBHH", 0, 100, name_len, 255, 4680, 0), dtype=np.uint8)
+    rec[:, 4:4 + len(fixed)] = fixed
+    flags = np.empty(2 * n, dtype="<u2")
+    flags[0::2] = 0x1 | 0x2 | 0x40 | 0x20
+    flags[1::2] = 0x1 | 0x2 | 0x80 | 0x10
+    rec[:, 18:20] = flags.view(np.uint8).reshape(-1, 2)
+    rec[:, 20:24] = np.frombuffer(struct.pack("<i", L), dtype=np.uint8)
+    rec[:, 24:36] = np.frombuffer(struct.pack("<iii", 0, 300, 200), dtype=np.uint8)
+    o = 36
+    idx = np.repeat(np.arange(n, dtype=np.int64), 2)
+    rec[:, o] = ord("q")
+    for d in range(10):
+        rec[:, o + 1 + 9 - d] = (idx // 10 ** d) % 10 + ord("0")
+    o += name_len
+    seq = np.empty((2 * n, L), dtype=np.uint8)
+    seq[0::2] = r1
+    seq[1::2] = r2
+    c4 = code[seq]
+    if L & 1:
+        c4 = np.concatenate([c4, np.zeros((2 * n, 1), dtype=np.uint8)], axis=1)
+    rec[:, o:o + (L + 1) // 2] = (c4[:, 0::2] << 4) | c4[:, 1::2]
+    o += (L + 1) // 2
+    rec[:, o:o + L] = 37
+    o += L
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_umi = (n + per_umi - 1) // per_umi
+    umis = acgt[rng.integers(0, 4, size=(n_umi, 10))]
+    cells = acgt[rng.integers(0, 4, size=(max(n_umi // 50, 1), 16))]
+    umi_of = np.repeat(np.arange(n_umi), per_umi)[:n]
+    cell_of = rng.integers(0, len(cells), size=n)
+    u2, c2 = np.repeat(umi_of, 2), np.repeat(cell_of, 2)
+    rec[:, o:o + 3] = np.frombuffer(b"CBZ", dtype=np.uint8); o += 3
+    rec[:, o:o + 16] = cells[c2]; o += 16
+    rec[:, o:o + 3] = np.frombuffer(b"-1\x00", dtype=np.uint8); o += 3
+    for tag in (b"UBZ", b"URZ"):
+        rec[:, o:o + 3] = np.frombuffer(tag, dtype=np.uint8); o += 3
+        rec[:, o:o + 10] = umis[u2]; o += 10
+        rec[:, o] = 0; o += 1
+    assert o == 4 + body_len
+    text = b"@HD\tVN:1.6\tSO:unknown\n@SQ\tSN:chr1\tLN:100000\n"
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\x00" + struct.pack("<i", 100000)
+    raw = head + rec.tobytes()
+    parts = [raw[lo:lo + 60000] for lo in range(0, len(raw), 60000)]
+    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 2)) as pool, open(path, "wb") as f:
+        for blob in pool.imap(_block, parts, chunksize=64):
+            f.write(blob)
+        f.write(_block(b""))
+    return len(raw)
+
+
+if __name__ == "__main__":
+    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    per_umi = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    d = tempfile.mkdtemp(prefix="nimble_bam_", dir="/tmp")
+    names, seqs = synth.make_library(1000)
+    synth.write_library(d + "/lib.json", names, seqs)
+    r1, r2 = synth.make_reads(seqs, pairs, paired=True)
+    t = time.time()
+    raw = write_bam(d + "/in.bam", r1, r2, per_umi, np.random.default_rng(3))
+    print("%d pairs in UMI groups of %d pairs: %.2f GB of BAM records, %.2f GB file (%.0f s to write)" % (
+        pairs, per_umi, raw / 1e9, os.path.getsize(d + "/in.bam") / 1e9, time.time() - t), flush=True)
+    exe = "nimble-aligner_amd/lib/nimble"
+    for rep in range(2):
+        t = time.time()
+        cp = subprocess.run([exe, "-r", d + "/lib.json", "-o", d + "/out.tsv.gz", "-i", d + "/in.bam"], capture_output=True, text=True,
+                            env=dict(os.environ, NIMBLE_HOST_TIMING="1"))
+        wall = time.time() - t
+        assert cp.returncode == 0, cp.stderr[-800:]
+        lines = [l for l in cp.stderr.splitlines() if l.startswith("[nimble")]
+        print("run %d: wall %.2f s = %.2f M reads/s (process start, index build and HIP init included); output %.1f MB" % (
+            rep, wall, 2 * pairs / wall / 1e6, os.path.getsize(d + "/out.tsv.gz") / 1e6), flush=True)
+        for l in lines[-6:]:
+            print("    " + l, flush=True)
+    subprocess.run(["rm", "-rf", d])
