@@ -26,9 +26,6 @@ def run(tag, env, reps=3):
     if cons: print("      " + cons[-1], flush=True)
 run("defaults", {})
 run("buffers not page-locked", {"NIMBLE_FASTQ_NO_PIN": "1"})
-run("12 parser threads", {"NIMBLE_FASTQ_THREADS": "12"})
-run("14 parser threads", {"NIMBLE_FASTQ_THREADS": "14"})
-run("20 parser threads", {"NIMBLE_FASTQ_THREADS": "20"})
 run("ASCII batches (no host packing)", {"NIMBLE_FASTQ_PACK": "0"})
 subprocess.run(["rm", "-rf", d])
 PY
