@@ -7,6 +7,7 @@ import importlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -102,3 +103,33 @@ def test_cli_takes_a_bam_file(tmp_path):
     exp = ora.call_umi(ora.Index.from_reference(ref), ref, cfg, inp["r1"], inp["o1"], inp["r2"], inp["o2"], q1=inp["q1"],
                        q2=inp["q2"], skip1=inp["skip1"], skip2=inp["skip2"], segment=inp["seg"], keep_per_read=True)
     assert bam_util.check_output(text, groups, inp, exp) > 50
+
+
+def test_large_output_is_one_gzip_member_and_batches_do_not_matter(tmp_path, monkeypatch):
+    # an output of several deflate blocks (written by a pool, pigz fashion) must still be ONE valid gzip member, as
+    # flate2's GzEncoder writes it, and cutting the input into device calls anywhere must not change a byte of the text
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gzip
+    import subprocess
+    import e2e_bam
+    names, seqs = synth.make_library(64)
+    lib = str(tmp_path / "lib.json")
+    synth.write_library(lib, names, seqs)
+    r1, r2 = synth.make_reads(seqs, 40000, paired=True, seed=5)
+    bam = str(tmp_path / "in.bam")
+    e2e_bam.write_bam(bam, r1, r2, 8, np.random.default_rng(3))
+    exe = os.path.join(ROOT, "nimble-aligner_amd", "lib", "nimble")
+    texts = []
+    for batch in ("3000", "100000000"):
+        out = str(tmp_path / ("out_%s.tsv.gz" % batch))
+        cp = subprocess.run([exe, "-r", lib, "-o", out, "-i", bam], capture_output=True, text=True,
+                            env=dict(os.environ, NIMBLE_BAM_BATCH=batch))
+        assert cp.returncode == 0, cp.stderr[-500:]
+        assert "Validation successful" in cp.stdout
+        raw = open(out, "rb").read()
+        assert raw.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff") == 1
+        assert subprocess.run(["gzip", "-t", out]).returncode == 0
+        texts.append(gzip.open(out).read())
+    assert len(texts[0]) > (4 << 20)          # several 1 MiB blocks
+    assert texts[0] == texts[1]
+    assert texts[0].split(b"\n", 1)[0].count(b"\t") + 1 == 84
