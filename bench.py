@@ -214,7 +214,7 @@ def main():
             # pack -> route by key hash (device kernels) -> all-to-all of the records -> finish per rank
             # -> all-reduce of the counts over the agreed callset table
             return nd.sharded_step(lib, r1, None, n, L, device, reducer)
-        return lib.score_call_raw(r1, r2, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+        return lib.score_call_raw(r1, None, r2, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count (read set 0; the
     # sets are draws of one recipe and agree to a fraction of a percent)
@@ -231,7 +231,7 @@ def main():
 
     def begin(slot, k):
         r1, r2 = sets[k % n_sets]
-        lib.score_call_begin(slot, r1, r2, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
+        lib.score_call_begin(slot, r1, None, r2, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     def end(slot):
         r = lib.score_call_end(slot, raw=True)
@@ -437,7 +437,7 @@ def main():
                      None if not paired else synth.fixed_offsets(S1, L), n_threads=1)
             cpu1_s = time.perf_counter() - t1
             # parity on the sample: the GPU table must equal the oracle's table
-            got = lib.score_call(r1[:S].contiguous(), None if not paired else r2[:S].contiguous(), n=S, fixed_len=L,
+            got = lib.score_call(r1[:S].contiguous(), None, None if not paired else r2[:S].contiguous(), None, n=S, fixed_len=L,
                                  max_len=L, mem=nim.MEM_DEVICE)
             parity = [(f, c) for f, c in got] == [(f, c) for f, c in ores.rows]
             if not parity:

@@ -81,15 +81,18 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_pack(const uint8_t *__restrict__
     uint64_t e = off ? off[r0 + cnt] : (r0 + cnt) * fixed_len;
     // offsets handed over in device memory were never seen by the host: a span that does not fit the tile (non-monotone
     // offsets, a read longer than max_len) is cut here and reported through the call's error word
+    bool bad_span = false;
     if (e < s || e - s > (uint64_t)cnt * max_len) {
       e = s;
+      bad_span = true;
       if (tid == 0) atomicOr((unsigned long long *)&cb.state[14], 1ULL);
     }
     uintptr_t a = (uintptr_t)(src + s);
     uintptr_t a0 = a & ~(uintptr_t)15;
     shift[m] = (uint32_t)(a - a0);
     seg_start[m] = s;
-    uint32_t nvec = (uint32_t)((e - s + shift[m] + 15) >> 4);
+    // (a span that made no sense is not touched at all: its start is as untrustworthy as its length)
+    uint32_t nvec = bad_span ? 0u : (uint32_t)((e - s + shift[m] + 15) >> 4);
     uint4 *dst = reinterpret_cast<uint4 *>(lds + (size_t)m * tile_bytes);
     const uint4 *g = reinterpret_cast<const uint4 *>(a0);
     // 16 B / lane, coalesced, written to LDS by the load itself (global_load_lds_dwordx4: wave-uniform LDS base +
