@@ -213,7 +213,7 @@ def main():
         if sharded:
             # pack -> route by key hash (device kernels) -> all-to-all of the records -> finish per rank
             # -> all-reduce of the counts over the agreed callset table
-            return nd.sharded_step(lib, r1, None, n, L, device, reducer)
+            return nd.sharded_step(lib, r1, r2, n, L, device, reducer)
         return lib.score_call_raw(r1, None, r2, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
     # one untimed pass with the work counters on: gives P / U / sum(E) for the algorithmic byte count (read set 0; the
@@ -253,7 +253,7 @@ def main():
         for s_ in range(4 if args.form == "local" else 3):
             lib.device_context(s_).set_counters(False)
         for w in range(max(args.warmup, 3)):   # allocates the other call slots and the utility context
-            pipe.submit(sets[w % n_sets][0], None, n, L)
+            pipe.submit(sets[w % n_sets][0], sets[w % n_sets][1], n, L)
         for r in pipe.flush():
             rows = r
     if sharded:
@@ -265,7 +265,7 @@ def main():
     if sharded and not args.no_pipeline:
         # software-pipelined multi-GPU steps: K submits + the drain all end inside the timed region
         for i in range(args.steps):
-            r = pipe.submit(sets[i % n_sets][0], None, n, L)
+            r = pipe.submit(sets[i % n_sets][0], sets[i % n_sets][1], n, L)
             if r is not None:
                 rows = r
                 marks.append(time.perf_counter())
