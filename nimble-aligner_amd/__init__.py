@@ -202,6 +202,18 @@ def _ptr(x):
     raise TypeError(type(x))
 
 
+def _off(x):
+    """pointer of a read-offsets argument: 8-byte integers or None.  (Two byte tensors handed over positionally -- mates in
+    the place of the offsets -- once went all the way to the device, which read bases as offsets.)"""
+    if x is None or isinstance(x, int):
+        return x
+    size = x.dtype.itemsize if isinstance(x, np.ndarray) else (x.element_size() if hasattr(x, "element_size") else 8)
+    if size != 8:
+        raise TypeError("read offsets must be 64-bit integers (n + 1 of them); got elements of %d bytes -- are the mates in "
+                        "the place of the offsets?" % size)
+    return _ptr(x)
+
+
 def key_words(max_len, paired):
     """u64 words of one packed read key (nimble_key_words)."""
     return int(hip_lib().nimble_key_words(int(max_len), int(bool(paired))))
@@ -297,7 +309,7 @@ class Context:
             else:
                 max_len = fixed_len
         self._keep = (r1, r1_off, r2, r2_off)  # keep device inputs alive until the next call
-        _check(hip_lib().nimble_call(self.h, C.byref(params), _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+        _check(hip_lib().nimble_call(self.h, C.byref(params), _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n,
                                      fixed_len, max_len, mem))
         self.n = n
 
@@ -323,7 +335,7 @@ class Context:
         ex.trim_strictness = trim_strictness
         ex.trim_target_length = trim_target_length
         self._keep = (r1, r1_off, r2, r2_off, segment, qual, skip)
-        _check(hip_lib().nimble_call_ex(self.h, C.byref(params), _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+        _check(hip_lib().nimble_call_ex(self.h, C.byref(params), _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n,
                                         fixed_len, max_len, mem, C.byref(ex)))
         self.n = n
 
@@ -354,7 +366,7 @@ class Context:
         if r1_off is not None and n is None:
             n = int(len(r1_off) - 1)
         self._keep = (r1, r1_off, r2, r2_off)
-        _check(hip_lib().nimble_stream_append(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+        _check(hip_lib().nimble_stream_append(self.h, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n, fixed_len,
                                               mem))
         self.n += n
 
@@ -838,7 +850,7 @@ class Library:
             else:
                 max_len = fixed_len
         h = C.c_void_p()
-        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n, fixed_len,
                                              max(max_len, 1), mem, C.byref(h)))
         return _rows(h)
 
@@ -848,7 +860,7 @@ class Library:
         if r1_off is not None and n is None:
             n = int(len(r1_off) - 1)
         h = C.c_void_p()
-        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+        _hcheck(host_lib().nimble_score_call(self.h, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n, fixed_len,
                                              max(max_len or fixed_len, 1), mem, C.byref(h)))
         return RowsHandle(h)
 
@@ -862,7 +874,7 @@ class Library:
             max_len = int(np.diff(r1_off.astype(np.int64)).max())
             if r2_off is not None:
                 max_len = max(max_len, int(np.diff(r2_off.astype(np.int64)).max()))
-        _hcheck(host_lib().nimble_score_call_begin(self.h, slot, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+        _hcheck(host_lib().nimble_score_call_begin(self.h, slot, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n,
                                                    fixed_len, max(max_len or fixed_len, 1), mem))
 
     def score_call_begin_words(self, slot, w1, len1, stride1, w2=None, len2=None, stride2=0, n=None, max_len=0,
@@ -900,7 +912,7 @@ class Library:
             ex.skip[m] = _ptr(skip[m])
         h = C.c_void_p()
         L = host_lib()
-        _hcheck(L.nimble_score_call_umis(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n, fixed_len,
+        _hcheck(L.nimble_score_call_umis(self.h, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n, fixed_len,
                                          max(max_len or fixed_len, 1), mem, C.byref(ex), int(per_read), C.byref(h)))
         try:
             rows = []
@@ -928,7 +940,7 @@ class Library:
         if r1_off is not None and n is None:
             n = int(len(r1_off) - 1)
         self._keep = (r1, r1_off, r2, r2_off)
-        _hcheck(host_lib().nimble_score_stream_append(self.h, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+        _hcheck(host_lib().nimble_score_stream_append(self.h, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n,
                                                       fixed_len, mem))
 
     def stream_end(self, raw=False):
@@ -953,7 +965,7 @@ class Library:
         max_len = max(max_len or fixed_len, 1)
         pt = out if out is not None and out.n == n else PackedTensors.empty(n, max_len, r2 is not None, device)
         st = pt.as_struct()
-        _hcheck(host_lib().nimble_library_pack_slot(self.h, slot, _ptr(r1), _ptr(r1_off), _ptr(r2), _ptr(r2_off), n,
+        _hcheck(host_lib().nimble_library_pack_slot(self.h, slot, _ptr(r1), _off(r1_off), _ptr(r2), _off(r2_off), n,
                                                     fixed_len, max_len, mem, C.byref(st)))
         return pt
 

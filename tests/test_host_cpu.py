@@ -480,3 +480,13 @@ def test_packed_batch_reader_same_records_as_the_line_reader(tmp_path, monkeypat
     bad.write_bytes(b"@a\nAC\n+\nII\n@b\nGG\n+\nII\nnot a header\nAC\n+\nII\n")
     with pytest.raises(nim.Panic, match="Input R1 data malformed.: Unable to read sequence"):
         nim.read_fastq_packed_stats(str(bad), 2)
+
+
+def test_offsets_argument_refuses_byte_arrays():
+    # the mates handed over where the offsets belong (two positional byte arrays) are refused in the binding
+    lib = nim.Library(os.path.join(GOLDEN, "libraries", "basic.json"), "unstranded")
+    a = np.zeros(300, dtype=np.uint8)
+    with pytest.raises(TypeError, match="64-bit"):
+        lib.score_call(a, a, n=2, fixed_len=150)
+    with pytest.raises(TypeError, match="64-bit"):
+        lib.score_call_begin(0, a, a, n=2, fixed_len=150)

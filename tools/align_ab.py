@@ -53,7 +53,7 @@ if os.environ.get("AB_SORT", "0") != "0" and not PAIRED:
 sig = None
 for rep in range(REP):
     ctx.set_counters(rep == 0)
-    rows = lib.score_call_raw(reads, mates, n=N, fixed_len=150, max_len=150, mem=nim.MEM_DEVICE)
+    rows = lib.score_call_raw(reads, None, mates, None, n=N, fixed_len=150, max_len=150, mem=nim.MEM_DEVICE)
     t = ctx.timing()
     import hashlib
     s = hashlib.sha1(repr(rows.to_list()).encode()).hexdigest()
