@@ -186,6 +186,8 @@ def main():
     paired = wl["paired"]
     if paired and sharded:
         raise SystemExit("bench.py: the paired-end workload is a single-GPU configuration (BASELINE.json configs[3])")
+    if T < wl["family"] or T % wl["family"]:
+        raise SystemExit("bench.py: --features must be a multiple of the workload's family size (%d)" % wl["family"])
     if wl["family"] > 4:
         names, seqs = synth.make_family_library(T, wl["family"])
     else:
