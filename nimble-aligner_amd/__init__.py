@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# NIMBLE_LIB_DIR selects another build of both libraries (A/B runs of whole builds: libv/<name>/)
+LIB_DIR = os.environ.get("NIMBLE_LIB_DIR") or os.path.join(_HERE, "lib")
 # NIMBLE_HIP_LIB selects another build of the same library (A/B runs of kernel variants)
 HIP_LIB_PATH = os.environ.get("NIMBLE_HIP_LIB") or os.path.join(LIB_DIR, "libnimble_hip.so")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_host.so")

@@ -97,14 +97,14 @@ struct nimble_index {
   hipStream_t intern_last = nullptr;  // the stream ev_intern was last recorded on
   bool released = false;  // nimble_index_free was called while contexts were alive: the last context frees the index
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_l1, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_intern) (void)hipEventDestroy(ev_intern);
-    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
+    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
                       &b_dyn_state})
       b->release();
   }
@@ -712,6 +712,8 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   up(ix->b_bitmap, fi.bitmap);
   static const bool use_l1 = env_u64("NIMBLE_FILTER_L1", 1) != 0;
   if (use_l1 && !fi.l1.empty()) up(ix->b_l1, fi.l1);
+  static const bool use_mleft = env_u64("NIMBLE_LOCAL_RESEED", 1) != 0;
+  if (use_mleft && !fi.mleft.empty()) up(ix->b_mleft, fi.mleft);
   up(ix->b_rec, fi.node_rec);
   up(ix->b_ledge, fi.node_ledge);
   up(ix->b_unitig, fi.unitig);
@@ -748,6 +750,8 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.bitmap = ix->b_bitmap.as<uint4>();
   d.bm_lines_log2 = fi.bm_lines_log2;
   d.l1 = ix->b_l1.p ? ix->b_l1.as<uint32_t>() : nullptr;
+  d.mleft = ix->b_mleft.p ? ix->b_mleft.as<uint64_t>() : nullptr;
+  d.mleft_log2 = fi.mleft_log2;
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
@@ -1887,6 +1891,9 @@ int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score
   if (counted) HIPCHK(hipMemcpy(counted, c->cb.counted, n, hipMemcpyDeviceToHost));
   return NIMBLE_OK;
 }
+
+// development aid, not part of the ABI in include/nimble_hip.h: section clocks of k_align in a profiling build
+extern "C" int nimble_debug_sections(uint64_t out[16], int reset) { return debug_sections(out, reset); }
 
 int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
   if (!c || !out) return fail(NIMBLE_E_INVALID, "NULL argument");

@@ -365,6 +365,38 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     if (out.l1_density > 0.5) std::vector<uint32_t>().swap(out.l1);
   }
   timer.lap("presence filter");
+  {
+    // 29-mers with more than one left flank: the sorted k-mers fall into four runs by their first base, each run sorted
+    // by the 29 bases behind it -- a four-way merge finds the 29-mers that head more than one run
+    const uint64_t SUF = (1ULL << (2 * (KMER - 1))) - 1ULL;
+    size_t at[5];
+    for (uint64_t b = 0; b <= 4; ++b)
+      at[b] = b == 4 ? n : (size_t)(std::lower_bound(kmers.begin(), kmers.end(), b << (2 * (KMER - 1))) - kmers.begin());
+    size_t cur[4] = {at[0], at[1], at[2], at[3]};
+    std::vector<uint64_t> multi;
+    for (;;) {
+      uint64_t lo = ~0ULL;
+      for (int b = 0; b < 4; ++b)
+        if (cur[b] < at[b + 1] && (kmers[cur[b]] & SUF) < lo) lo = kmers[cur[b]] & SUF;
+      if (lo == ~0ULL) break;
+      int heads = 0;
+      for (int b = 0; b < 4; ++b)
+        if (cur[b] < at[b + 1] && (kmers[cur[b]] & SUF) == lo) {
+          ++heads;
+          ++cur[b];
+        }
+      if (heads > 1) multi.push_back(lo);
+    }
+    out.n_mleft = multi.size();
+    out.mleft_log2 = 9;  // 32 table bits per entry, at least 4 KiB
+    while (out.mleft_log2 < 26 && (64ULL << out.mleft_log2) < 32ULL * multi.size()) ++out.mleft_log2;
+    out.mleft.assign((size_t)1 << out.mleft_log2, 0ULL);
+    for (uint64_t s29 : multi) {
+      const uint32_t h = mleft_hash(s29);
+      out.mleft[h >> (32u - out.mleft_log2)] |= (1ULL << (h & 63u)) | (1ULL << ((h >> 6) & 63u));
+    }
+  }
+  timer.lap("left-flank set");
   // 7. class descriptors
   out.cls_desc.assign(out.n_colours * 4, 0);
   for (size_t c = 0; c < out.n_colours; ++c) {

@@ -64,6 +64,24 @@ NIMBLE_HD uint64_t round_shared_of_kmer(uint64_t km, uint32_t j) {
   return (km >> (2u * (30u - start - SCAN_SHARED))) & ((1ULL << (2u * SCAN_SHARED)) - 1ULL);
 }
 
+// "Several left flanks" set (local re-seed of the walk, kernels.hip): the 29-mers S for which MORE THAN ONE base b makes
+// b.S a library k-mer, as a small Bloom table (two bits in one 64-bit word).  A walk that broke on read base p inside a
+// unitig knows that a.S is in the library (a = the unitig's base there, S = the 29 bases behind it, equal in read and
+// graph); when S is not in this set, a is the ONLY such base, so the read's k-mer at p (its own base b != a, then S) is
+// absent -- without asking the dictionary or the presence filter.
+NIMBLE_HD uint32_t mleft_hash(uint64_t s29) {
+  uint32_t f = (uint32_t)s29 ^ (uint32_t)(s29 >> 27);
+  f *= 0x85EBCA6Bu;
+  f ^= f >> 15;
+  f *= 0xC2B2AE35u;
+  return f ^ (f >> 13);
+}
+NIMBLE_HD bool mleft_maybe(const uint64_t *table, uint32_t log2_words, uint64_t s29) {
+  const uint32_t h = mleft_hash(s29);
+  const uint64_t w = table[h >> (32u - log2_words)];
+  return ((w >> (h & 63u)) & (w >> ((h >> 6) & 63u)) & 1ULL) != 0;
+}
+
 // content hash of an equivalence class (ascending ids); streaming form
 NIMBLE_HD uint64_t class_hash_init() { return 0x9E3779B97F4A7C15ULL; }
 NIMBLE_HD uint64_t class_hash_step(uint64_t h, uint32_t id) {
@@ -129,6 +147,10 @@ struct FlatIndex {
   // first level of the filter: one bit per value of the 12 shared bases (empty when more than half the bits are set)
   std::vector<uint32_t> l1;
   double l1_density = 0.0;
+  // 29-mers with several left flanks among the library k-mers (mleft_maybe): 2^mleft_log2 words
+  std::vector<uint64_t> mleft;
+  uint32_t mleft_log2 = 0;
+  uint64_t n_mleft = 0;
   // node record, one 64-byte line per unitig so that a hop costs one dependent memory level and the
   // class intersection needs no load at all:
   //   u32[0]      = len (bases, low 24 bits) | exts (lext | rext<<4) << 24

@@ -23,6 +23,8 @@ struct DevIndex {
   const uint4 *bitmap;      // round-anchored presence filter, one 128-bit line per uint4 (flat_index.h)
   uint32_t bm_lines_log2;
   const uint32_t *l1;       // may be NULL: first level of the filter, one bit per value of the 12 shared bases (2 MiB)
+  const uint64_t *mleft;    // may be NULL: 29-mers with several left flanks (flat_index.h mleft_maybe); NULL = no local re-seed
+  uint32_t mleft_log2;
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;
@@ -128,6 +130,8 @@ void launch_clear_call(hipStream_t s, const CallBuffers &cb);  // histogram tabl
 void launch_publish_state(hipStream_t s, const uint64_t *state, uint64_t *host);  // host: page-locked, 16 words
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
 
+// debug builds (-DNIMBLE_PROFILE_SECTIONS=1): clock cycles per section of k_align; returns 0 when not compiled in
+int debug_sections(uint64_t out[16], int reset);
 uint32_t align_ws_lanes();   // lanes of the align grid (sizes ws_cols)
 uint32_t align_lds_cols();   // visited colours kept in LDS before spilling to ws_cols
 

@@ -39,6 +39,24 @@ constexpr int LDS_COLS = 4;
 constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds
 constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
 
+// NIMBLE_PROFILE_SECTIONS (debug builds only, tools/build_variant.sh prof -DNIMBLE_PROFILE_SECTIONS=1): wave clock cycles
+// per section of k_align, summed over all waves into g_prof (read with nimble_debug_sections).
+#ifndef NIMBLE_PROFILE_SECTIONS
+#define NIMBLE_PROFILE_SECTIONS 0
+#endif
+#if NIMBLE_PROFILE_SECTIONS
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = clock64();
+#define PROF(i) { const unsigned long long prof_n = clock64(); prof_acc[i] += prof_n - prof_t; prof_t = prof_n; }
+#define PROF_ARGS , unsigned long long *prof_acc, unsigned long long &prof_t
+#define PROF_PASS , prof_acc, prof_t
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_ARGS
+#define PROF_PASS
+#endif
+
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t x = v;
@@ -430,6 +448,31 @@ __device__ __forceinline__ uint64_t ld_stream(const uint64_t *p) { return __buil
 template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
 #endif
 
+// 16-byte gathers from the dictionary and the presence filter (tables beyond L2).  NIMBLE_GATHER_POLICY (experiments
+// only) issues them with explicit cache-policy bits: 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1 nt.
+#ifndef NIMBLE_GATHER_POLICY
+#define NIMBLE_GATHER_POLICY 0
+#endif
+__device__ __forceinline__ uint4 ld_gather(const uint4 *p) {
+#if NIMBLE_GATHER_POLICY == 0
+  return *p;
+#else
+  uint4 v;
+#if NIMBLE_GATHER_POLICY == 1
+  asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#elif NIMBLE_GATHER_POLICY == 2
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#elif NIMBLE_GATHER_POLICY == 3
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#elif NIMBLE_GATHER_POLICY == 4
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#else
+  asm volatile("global_load_dwordx4 %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#endif
+  return v;
+#endif
+}
+
 // nb (1..32) bases of the lane's key starting at base `pos`, right-aligned
 // (branch-free: a shift by 64 - s is split into 1 + (63 - s) so that s = 0 needs no special case -- the branch the
 // compiler made of `s ? ... : hi` sat in the innermost loop of the walk; the column has a zero word behind the key)
@@ -483,7 +526,7 @@ __device__ __forceinline__ bool probe_direct(const DevIndex &ix, Lane &ln, uint3
                                              uint32_t &off) {
   const uint64_t km = lds_bits(ln.rd, base0 + pos, KMER);
   const uint64_t h = kmer_slot(km, ix.ht_log2);
-  const uint4 s = ix.ht[h];
+  const uint4 s = ld_gather(ix.ht + h);
   const uint64_t key = u64of(s.x, s.y);
   ln.probes++;
   if (key == km) { off = s.z; node = s.w; return true; }
@@ -511,7 +554,7 @@ __device__ __forceinline__ uint32_t round_maybe(const DevIndex &ix, const uint64
   }
   const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
   const uint64_t tail = extra ? (lds_bits(rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
-  const uint4 line = ix.bitmap[round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2)];
+  const uint4 line = ld_gather(ix.bitmap + round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2));
   const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
 #pragma unroll
   for (int i = 0; i < (int)SCAN_ROUND; ++i) {
@@ -543,7 +586,7 @@ __device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_
     const uint32_t p = kmer_pos + 3u * i;
     const uint64_t km = lds_bits(ln.rd, base0 + p, KMER);
     const uint64_t h = kmer_slot(km, ix.ht_log2);
-    const uint4 sl = ix.ht[h];
+    const uint4 sl = ld_gather(ix.ht + h);
     const uint64_t key = u64of(sl.x, sl.y);
     uint64_t v = u64of(sl.z, sl.w);
     bool hit = key == km;
@@ -575,7 +618,7 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
   if (!skip_direct) {
     const uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
     const uint64_t h = kmer_slot(km, ix.ht_log2);
-    const uint4 s = ix.ht[h];
+    const uint4 s = ld_gather(ix.ht + h);
     const uint64_t key = u64of(s.x, s.y);
     ln.probes++;
     if (key == km) { off = s.z; node = s.w; return true; }
@@ -719,7 +762,7 @@ __device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const NodeRec &nr, c
 // pre: result of a direct probe of position 0 already made for this mate (by the tile partition step):
 // 0 = none made, 1 = miss, 2 = hit with pre_seed = node << 32 | offset
 __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed, uint32_t &coverage,
-                     uint32_t &mismatches, uint32_t pre, uint64_t pre_seed) {
+                     uint32_t &mismatches, uint32_t pre, uint64_t pre_seed PROF_ARGS) {
   ln.n_cols = 0;
   ln.walk_nodes = 0;
   if (L < KMER) return false;
@@ -730,6 +773,7 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   uint32_t node = 0, koff = 0;
   bool first = true, done = false, need_seed = true;
   do {
+    PROF(3)
     if (need_seed) {  // SEED phase
       need_seed = false;
       bool have;
@@ -777,20 +821,40 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
     // most 32 bases) + (leave the unitig, if that stretch was its last).  With a loop per unitig around a loop per stretch
     // the wave ran max-over-lanes stretches for every unitig (5 x 8 iterations for reads that need 8 each); here a lane
     // takes as many iterations as it has stretches, whatever unitigs they fall in.
-    bool need_node = true;
+    //
+    // LOCAL RE-SEED (tent / tneed).  A compare that breaks on read base p leaves the reference searching its next seed at
+    // p, p + 3, ...  For a read with a substitution that seed is the k-mer at p + 3, three bases further down the very
+    // path the walk is on -- so instead of a filter line and a dictionary probe (two fetches from beyond L2, one behind
+    // the other) the walk goes on TENTATIVELY: it skips base p and compares the next 32 bases against the graph, hopping
+    // unitigs by the read's bases as usual, without counting anything.  When all 32 agree,
+    //   * the k-mer at p + 3 is the graph's k-mer at that place (every k-mer has one place in the graph): the seed the
+    //     reference finds, in the unitig the last compared base lies in, ending at that base;
+    //   * the k-mer at p is absent: the 29 bases behind p are the graph's, the graph's k-mer there starts with another
+    //     base, and the "several left flanks" set (flat_index.h) says no second base makes a library k-mer with them.
+    // The walk then stands exactly where the reference's stands after that seed (probes + 2: p missed, p + 3 hit).  Any
+    // disagreement, a missing edge, a 29-mer that may have several flanks: back to p and to the general seed search.
+    // State of the lane inside this phase: ST_IN = inside a unitig, ST_ENTER = stands at the head of `node` (offset koff),
+    // ST_SEED = needs the general seed search, ST_DONE.  (One integer instead of a handful of flags: every flag that lives
+    // across divergent branches is a lane mask the compiler has to patch at each of them.)
+    // tneed: bases the tentative walk has still to compare; NO_TENT (huge) outside it, so that one three-way minimum
+    // bounds a stretch in both modes, and counting it down everywhere is harmless.
+    PROF(4)
+    enum : uint32_t { ST_IN = 0, ST_ENTER = 1, ST_SEED = 2, ST_DONE = 3 };
+    constexpr uint32_t NO_TENT = 0x40000000u;
+    uint32_t st = done ? ST_DONE : ST_ENTER, tneed = NO_TENT;
     NodeRec nr;
     uint32_t upos = 0, n_left = 0, seen = 0;
-    while (!done && !need_seed) {
-      if (need_node) {
-        need_node = false;
+    while (st < ST_SEED) {
+      if (st == ST_ENTER) {
+        st = ST_IN;
         nr = load_node(ix, node);
         kmer_pos += KMER;
         cov += KMER;
-        push_col(ln, nr.q0.y, nr_desc(nr));
-        const uint32_t remaining = L - kmer_pos;
         upos = koff + KMER;
-        const uint32_t informative = nr_len(nr) - upos;
-        n_left = remaining < informative ? remaining : informative;
+        if (tneed >= NO_TENT / 2) push_col(ln, nr.q0.y, nr_desc(nr));
+        const uint32_t remaining = L - kmer_pos, informative = nr_len(nr) - upos;
+        const uint32_t lim = remaining < informative ? remaining : informative;
+        n_left = lim < tneed ? lim : tneed;
         seen = 0;
       }
       bool prem = false;
@@ -800,7 +864,9 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t adv = c;
-        if (allowed == 0) {  // (uniform) the usual setting: the first mismatch ends the compare -- selects, no branch
+        if (allowed == 0 || tneed < NO_TENT / 2) {
+          // the usual setting, and the tentative walk under any setting: the first mismatch ends the compare --
+          // selects, no branch ((uniform) for allowed == 0)
           prem = cnt != 0;
           const uint32_t bit = 63u - (uint32_t)__clzll((long long)(m | 1ULL));
           adv = prem ? c - 1u - (bit >> 1) : c;
@@ -822,26 +888,51 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         cov += adv;
         kmer_pos += adv;
         upos += adv;
+        tneed -= adv;
       }
-      if (n_left == 0) {  // the unitig is done: on to its successor, a new seed, or the end
-        if (kmer_pos >= L) {
-          done = true;
+      if (n_left == 0) {  // the unitig, or the tentative stretch, is done: a successor, a new seed, or the end
+        const bool tent = tneed < NO_TENT / 2;
+        const uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);  // (the column ends in a zero word: safe at kmer_pos == L)
+        const bool edge = ((nr_exts(nr) >> 4) >> nbase) & 1u;
+        if (tent && !prem && tneed == 0) {
+          // all 32 bases behind p agree: the seed is the k-mer that ends with the last of them, in this unitig.  Enter it
+          // the way a seed is entered (the record comes from L1 this time): kmer_pos = p + 3, nothing counted so far.
+          koff = upos - KMER;
+          kmer_pos -= KMER;
+          cov -= 32u;
+          ln.probes += 2;
+          tneed = NO_TENT;
+          st = ST_ENTER;
+        } else if (!prem && kmer_pos < L && edge) {
+          node = sel4(nr.re, nbase);
+          koff = 0;
+          kmer_pos -= KMER - 1;
+          cov -= KMER - 1;
+          tneed -= 1;  // (tentative: the junction base agrees by the edge's label)
+          st = ST_ENTER;
+        } else if (tent) {  // a differing base, or the read leaves the graph: back to p, general search
+          kmer_pos -= 33u - tneed;
+          cov -= 32u - tneed;
+          mm -= prem ? 1u : 0u;
+          tneed = NO_TENT;
+          st = ST_SEED;
+        } else if (kmer_pos >= L || kmer_pos > last_kmer_pos) {
+          st = ST_DONE;
+        } else if (prem && ix.mleft && kmer_pos + 3u <= last_kmer_pos &&
+                   !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(ln.rd, base0 + kmer_pos + 1u, KMER - 1u))) {
+          tneed = 32;
+          kmer_pos += 1;
+          upos += 1;
+          const uint32_t rest = nr_len(nr) - upos;
+          n_left = rest < 32u ? rest : 32u;
         } else {
-          const uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);
-          if (!prem && ((nr_exts(nr) >> 4) & (1u << nbase))) {
-            node = sel4(nr.re, nbase);
-            koff = 0;
-            kmer_pos -= KMER - 1;
-            cov -= KMER - 1;
-            need_node = true;
-          } else if (kmer_pos > last_kmer_pos) {
-            done = true;
-          } else {
-            need_seed = true;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
-          }
+          st = ST_SEED;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
         }
       }
     }
+    PROF(5)
+    done = st == ST_DONE;
+    need_seed = st == ST_SEED;
   } while (!done);
   if (ln.walk_nodes == 0) return false;
   coverage = cov;
@@ -1026,6 +1117,9 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 #ifndef NIMBLE_ALIGN_WAVES
 #define NIMBLE_ALIGN_WAVES 8
 #endif
+#ifndef NIMBLE_RESULT_STAGED
+#define NIMBLE_RESULT_STAGED 1
+#endif
 // WIDE: the index has classes wider than the 64-row mask form (ix.all_local == 0): the visited colours are kept and
 // the intersection may go through intersect_general.  The other instantiation carries none of that code -- the
 // out-of-line call alone costs the walk registers around it.
@@ -1039,9 +1133,13 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
   const uint32_t tid = threadIdx.x;
   const uint32_t kw = cb.key_words;
   uint64_t *col = lds64 + tid;
+  constexpr int nm = PAIRED ? 2 : 1;
+  // rows of the LDS columns: the key words, a zero word behind them -- and at least nm + 1, because a finished tile
+  // leaves its results in the columns (below)
+  const uint32_t krows = kw + 1u > (uint32_t)nm + 1u ? kw + 1u : (uint32_t)nm + 1u;
   Lane ln;
   ln.rd = col;
-  ln.lc = reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) + tid;
+  ln.lc = reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) + tid;
   ln.ws_lanes = cb.ws_lanes;
   ln.ws_rows = cb.ws_rows;
   ln.ws = cb.ws_cols + ((uint64_t)blockIdx.x * ALIGN_BLOCK + tid);
@@ -1061,23 +1159,47 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
   ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
-  constexpr int nm = PAIRED ? 2 : 1;
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
 
   // small block-shared arrays behind the columns in the dynamic region (extern base stays 16-byte aligned)
-  uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)(kw + 1) * ALIGN_BLOCK) +
+  uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) +
                                                LDS_COLS * ALIGN_BLOCK);
   unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
   uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
   uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
+  uint64_t prev_tile = ~0ULL;
+  PROF_DECL
   for (;;) {
     // dynamic tile scheduling: tiles differ a lot in cost (off-target reads probe 41 times)
+    PROF(7)
     __syncthreads();
+    PROF(0)
+#if NIMBLE_RESULT_STAGED
+    // The results of the tile just finished sit in the LDS columns, one column per read in read order (the lanes worked
+    // on a permutation of the tile): written out here, every wave stores 64 consecutive reads per instruction -- whole
+    // lines instead of 64 scattered words per store that leave L2 as partial lines.
+    if (prev_tile != ~0ULL) {
+      const uint64_t rp = prev_tile * ALIGN_BLOCK + tid;
+      if (rp < n) {
+        const uint64_t rs = col[nm * ALIGN_BLOCK];
+#pragma unroll
+        for (int m = 0; m < nm; ++m) {
+          const uint64_t v = col[m * ALIGN_BLOCK];
+          st_stream(&cb.reason[m][rp], (uint8_t)(rs >> (8 * m)));
+          st_stream(&cb.score[m][rp], (uint32_t)(v & 0xFFFFu));
+          st_stream(&cb.mism[m][rp], (uint32_t)((v >> 16) & 0xFFFFu));
+          st_stream(&cb.cls[m][rp], (uint32_t)(v >> 32));
+        }
+      }
+    }
+#endif
     if (tid == 0) s_tile = atomicAdd((unsigned long long *)&cb.state[12], 1ULL);
     __syncthreads();
     const uint64_t tile = s_tile;
+    PROF(0)
     if (tile >= n_tiles) break;
+    prev_tile = tile;
     // ---- own slot: key into LDS column tid, first direct probe of mate 0
     const uint64_t r_own = tile * ALIGN_BLOCK + tid;
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
@@ -1108,6 +1230,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
     }
     // ---- partition the tile: reads that still need a scan first, then the seeded ones, then the rest, so
     // that the waves of the block are (nearly) homogeneous and most of them skip the scan rounds entirely
+    PROF(1)
     s_seed[tid] = seedv;
     {
       const uint64_t b0 = __ballot(kind == 0), b1 = __ballot(kind == 1);
@@ -1133,6 +1256,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
       s_perm[pos] = (uint16_t)tid;
       __syncthreads();
     }
+    PROF(2)
     const uint32_t slot = s_perm[tid];
     const uint64_t r = tile * ALIGN_BLOCK + slot;
     const bool active = r < n;
@@ -1148,6 +1272,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
       }
     }
     bool any_walk = false;
+    uint64_t res_v[2] = {0, 0}, res_r = 0;  // (staged results: score | mismatches << 16 | class << 32 per mate; reasons)
     for (int m = 0; m < nm; ++m) {
       uint32_t reason = NIMBLE_R_NONE, score = 0, mm = 0, cls = CLS_NONE;
       uint32_t need = 0, best_col = 0, best_len = 0;
@@ -1164,7 +1289,9 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
         } else {
           uint32_t cov = 0, mis = 0;
           const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
-          bool some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed);
+          PROF(3)
+          bool some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed PROF_PASS);
+          PROF(3)
           if (!some) {
             reason = NIMBLE_R_NO_MATCH;
           } else {
@@ -1228,6 +1355,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
         }
       }
       // wave-aggregated allocation of scratch space for classes that need interning (convergent point)
+      PROF(6)
       uint32_t total;
       uint32_t ofs = wave_excl_scan(need, total);
       unsigned long long base = 0;
@@ -1248,15 +1376,32 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
           cls = CLS_NONE;
         }
       }
+#if NIMBLE_RESULT_STAGED
+      res_v[m] = (uint64_t)score | ((uint64_t)mm << 16) | ((uint64_t)cls << 32);  // (a mate has at most 65 535 bases)
+      res_r |= (uint64_t)reason << (8 * m);
+#else
       if (active) {
         st_stream(&cb.reason[m][r], (uint8_t)reason);
         st_stream(&cb.score[m][r], score);
         st_stream(&cb.mism[m][r], mm);
         st_stream(&cb.cls[m][r], cls);
       }
+#endif
     }
+#if NIMBLE_RESULT_STAGED
+    if (active) {  // the lane's own column is free now: both mates are done with the key
+      uint64_t *c = lds64 + slot;
+#pragma unroll
+      for (int m = 0; m < nm; ++m) c[m * ALIGN_BLOCK] = res_v[m];
+      c[nm * ALIGN_BLOCK] = res_r;
+    }
+#endif
     if (any_walk) c_seeded++;
   }
+#if NIMBLE_PROFILE_SECTIONS
+  if ((tid & 63u) == 0)
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
   if (ln.overflow) atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_SCRATCH);
   if (want_counters) {
     uint64_t v2 = wave_sum64(ln.probes), v3 = wave_sum64(ln.nodes), v4 = wave_sum64(ln.entries);
@@ -1930,6 +2075,23 @@ inline uint32_t blocks_for(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 
 
 }  // namespace
 
+int debug_sections(uint64_t out[16], int reset) {
+#if NIMBLE_PROFILE_SECTIONS
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out[i] = h[i];
+  if (reset) {
+    for (int i = 0; i < 16; ++i) h[i] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 1;
+#else
+  (void)out;
+  (void)reset;
+  return 0;
+#endif
+}
+
 uint32_t align_ws_lanes() { return (uint32_t)ALIGN_GRID * ALIGN_BLOCK; }
 uint32_t align_lds_cols() { return LDS_COLS; }
 
@@ -1971,7 +2133,9 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
                   int want_counters, int grid_pct) {
   if (cb.n == 0) return;
   uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  size_t lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
+  const uint32_t min_rows = (cb.paired ? 2u : 1u) + 1u;  // a finished tile leaves its results in the columns
+  const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
+  size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter
   const bool wide = ix.all_local == 0;
