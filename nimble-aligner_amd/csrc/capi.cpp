@@ -97,14 +97,14 @@ struct nimble_index {
   hipStream_t intern_last = nullptr;  // the stream ev_intern was last recorded on
   bool released = false;  // nimble_index_free was called while contexts were alive: the last context frees the index
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rowseq, b_runs, b_occ, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_intern) (void)hipEventDestroy(ev_intern);
-    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
+    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rowseq, &b_runs, &b_occ, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
                       &b_dyn_state})
       b->release();
   }
@@ -180,6 +180,7 @@ struct nimble_ctx {
   bool called = false;
   int want_counters = 0;
   int align_grid_pct = 100;
+  int stream_cus = 0;  // CUs the launch stream is confined to (0 = all): the persistent align grid is sized to them
   uint32_t dyn_before = 0, dyn_after = 0;
   // arguments of the call in flight (kept so that finish_call can re-enqueue after growing a pool)
   nimble_align_params prm{};
@@ -496,7 +497,7 @@ int enqueue_call(nimble_ctx *c) {
     rc = enqueue_route(c);
     if (rc) return rc;
   }
-  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct);
+  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus);
   return enqueue_tail(c);
 }
 
@@ -714,6 +715,12 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   if (use_l1 && !fi.l1.empty()) up(ix->b_l1, fi.l1);
   static const bool use_mleft = env_u64("NIMBLE_LOCAL_RESEED", 1) != 0;
   if (use_mleft && !fi.mleft.empty()) up(ix->b_mleft, fi.mleft);
+  static const bool use_rows = env_u64("NIMBLE_FAST_WALK", 1) != 0;
+  if (use_rows && use_mleft && !fi.rowseq.empty() && !fi.mleft.empty()) {
+    up(ix->b_rowseq, fi.rowseq);
+    up(ix->b_runs, fi.runs);
+    up(ix->b_occ, fi.node_occ);
+  }
   up(ix->b_rec, fi.node_rec);
   up(ix->b_ledge, fi.node_ledge);
   up(ix->b_unitig, fi.unitig);
@@ -752,6 +759,9 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.l1 = ix->b_l1.p ? ix->b_l1.as<uint32_t>() : nullptr;
   d.mleft = ix->b_mleft.p ? ix->b_mleft.as<uint64_t>() : nullptr;
   d.mleft_log2 = fi.mleft_log2;
+  d.rowseq = ix->b_rowseq.p ? ix->b_rowseq.as<uint64_t>() : nullptr;
+  d.runs = ix->b_runs.as<uint4>();
+  d.node_occ = ix->b_occ.as<uint2>();
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
@@ -1596,7 +1606,7 @@ static int stream_flush_align(nimble_ctx *c, bool force) {
   const uint64_t pending = c->stream_n - c->align_from;
   if (pending == 0 || (!force && pending < STREAM_ALIGN_READS)) return NIMBLE_OK;
   HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
-  launch_align(c->stream, c->ix->dev, c->prm, stream_view(c, c->align_from, pending), c->want_counters, c->align_grid_pct);
+  launch_align(c->stream, c->ix->dev, c->prm, stream_view(c, c->align_from, pending), c->want_counters, c->align_grid_pct, c->stream_cus);
   HIPCHK(hipGetLastError());
   c->align_from = c->stream_n;
   return NIMBLE_OK;
@@ -1894,6 +1904,14 @@ int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score
 
 // development aid, not part of the ABI in include/nimble_hip.h: section clocks of k_align in a profiling build
 extern "C" int nimble_debug_sections(uint64_t out[16], int reset) { return debug_sections(out, reset); }
+// the 16 state words of the context's last finished call (kernels.h CallBuffers::state)
+extern "C" int nimble_debug_state(nimble_ctx *c, uint64_t out[16]) {
+  if (!c || !out || !c->called) return NIMBLE_E_INVALID;
+  int rc = finish_count_stage(c);
+  if (rc) return rc;
+  for (int i = 0; i < 16; ++i) out[i] = c->h_state[i];
+  return NIMBLE_OK;
+}
 
 int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
   if (!c || !out) return fail(NIMBLE_E_INVALID, "NULL argument");

@@ -25,6 +25,10 @@ struct DevIndex {
   const uint32_t *l1;       // may be NULL: first level of the filter, one bit per value of the 12 shared bases (2 MiB)
   const uint64_t *mleft;    // may be NULL: 29-mers with several left flanks (flat_index.h mleft_maybe); NULL = no local re-seed
   uint32_t mleft_log2;
+  // row space (flat_index.h): packed rows, runs (2 x uint4 each), one occurrence per unitig; rowseq == NULL: no fast walk
+  const uint64_t *rowseq;
+  const uint4 *runs;
+  const uint2 *node_occ;
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;
@@ -102,8 +106,9 @@ void launch_pack(hipStream_t s, const uint8_t *r1, const uint64_t *off1, const u
 void launch_pack_words(hipStream_t s, const uint64_t *w1, const uint32_t *len1, uint32_t stride1, const uint64_t *w2,
                        const uint32_t *len2, uint32_t stride2, uint32_t max_len, uint32_t min_len, const double *plog,
                        const CallBuffers &cb);
+// n_cus: CUs the stream may use (a CU-masked stream; 0 = the whole device): the persistent grid is sized to them
 void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct = 100);
+                  int want_counters, int grid_pct = 100, int n_cus = 0);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid = 0);  // 0 = one thread per read
