@@ -32,6 +32,9 @@ namespace nimble {
 
 namespace {
 
+#ifndef NIMBLE_TENT
+#define NIMBLE_TENT 1  // 0 (experiments): the local re-seed of walk() compiled out
+#endif
 constexpr int PACK_BLOCK = 256;
 #ifndef NIMBLE_ALIGN_BLOCK
 #define NIMBLE_ALIGN_BLOCK 256
@@ -842,11 +845,14 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
     // tneed: bases the tentative walk has still to compare; NO_TENT (huge) outside it, so that one three-way minimum
     // bounds a stretch in both modes, and counting it down everywhere is harmless.
     PROF(4)
-    enum : uint32_t { ST_IN = 0, ST_ENTER = 1, ST_SEED = 2, ST_DONE = 3 };
+    enum : uint32_t { ST_IN = 0, ST_ENTER = 1, ST_ENTER_T = 2, ST_SEED = 3, ST_DONE = 4 };
     constexpr uint32_t NO_TENT = 0x40000000u;
     uint32_t st = done ? ST_DONE : ST_ENTER, tneed = NO_TENT;
     NodeRec nr;
     uint32_t upos = 0, n_left = 0, seen = 0;
+    // (everything the tentative walk needs sits behind tests that fail for a lane outside it: on reads without a
+    // difference the loop costs what it cost before -- the first form, with the tests spread over the common path, took
+    // 10 % more time on exact reads)
     while (st < ST_SEED) {
       if (st == ST_ENTER) {
         st = ST_IN;
@@ -854,11 +860,18 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         kmer_pos += KMER;
         cov += KMER;
         upos = koff + KMER;
-        if (tneed >= NO_TENT / 2) push_col(ln, nr.q0.y, nr_desc(nr));
+        push_col(ln, nr.q0.y, nr_desc(nr));
         const uint32_t remaining = L - kmer_pos, informative = nr_len(nr) - upos;
-        const uint32_t lim = remaining < informative ? remaining : informative;
-        n_left = lim < tneed ? lim : tneed;
+        n_left = remaining < informative ? remaining : informative;
         seen = 0;
+      } else if (st == ST_ENTER_T) {  // a hop of the tentative walk: nothing is pushed, tneed bounds the stretch
+        st = ST_IN;
+        nr = load_node(ix, node);
+        kmer_pos += KMER;
+        cov += KMER;
+        upos = KMER;
+        const uint32_t informative = nr_len(nr) - upos;
+        n_left = tneed < informative ? tneed : informative;
       }
       bool prem = false;
       if (n_left) {
@@ -867,9 +880,10 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t adv = c;
-        if (allowed == 0 || tneed < NO_TENT / 2) {
-          // the usual setting, and the tentative walk under any setting: the first mismatch ends the compare --
-          // selects, no branch ((uniform) for allowed == 0)
+        // the usual setting, and the tentative walk under any setting: the first mismatch ends the compare
+        bool strict = allowed == 0;  // (uniform)
+        if (!strict) strict = tneed < NO_TENT / 2;
+        if (strict) {  // selects, no branch
           prem = cnt != 0;
           const uint32_t bit = 63u - (uint32_t)__clzll((long long)(m | 1ULL));
           adv = prem ? c - 1u - (bit >> 1) : c;
@@ -894,34 +908,40 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         tneed -= adv;
       }
       if (n_left == 0) {  // the unitig, or the tentative stretch, is done: a successor, a new seed, or the end
-        const bool tent = tneed < NO_TENT / 2;
         const uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);  // (the column ends in a zero word: safe at kmer_pos == L)
         const bool edge = ((nr_exts(nr) >> 4) >> nbase) & 1u;
-        if (tent && !prem && tneed == 0) {
-          // all 32 bases behind p agree: the seed is the k-mer that ends with the last of them, in this unitig.  Enter it
-          // the way a seed is entered (the record comes from L1 this time): kmer_pos = p + 3, nothing counted so far.
-          koff = upos - KMER;
-          kmer_pos -= KMER;
-          cov -= 32u;
-          ln.probes += 2;
-          tneed = NO_TENT;
-          st = ST_ENTER;
+        if (tneed < NO_TENT / 2) {  // inside the tentative walk
+          if (!prem && tneed == 0) {
+            // all 32 bases behind p agree: the seed is the k-mer that ends with the last of them, in this unitig.  Enter it
+            // the way a seed is entered (the record comes from L1 this time): kmer_pos = p + 3, nothing counted so far.
+            koff = upos - KMER;
+            kmer_pos -= KMER;
+            cov -= 32u;
+            ln.probes += 2;
+            tneed = NO_TENT;
+            st = ST_ENTER;
+          } else if (!prem && edge) {  // on along the read's base; the junction base agrees by the edge's label
+            node = sel4(nr.re, nbase);
+            kmer_pos -= KMER - 1;
+            cov -= KMER - 1;
+            tneed -= 1;
+            st = ST_ENTER_T;
+          } else {  // a differing base, or the read leaves the graph: back to p, general search
+            kmer_pos -= 33u - tneed;
+            cov -= 32u - tneed;
+            mm -= prem ? 1u : 0u;
+            tneed = NO_TENT;
+            st = ST_SEED;
+          }
         } else if (!prem && kmer_pos < L && edge) {
           node = sel4(nr.re, nbase);
           koff = 0;
           kmer_pos -= KMER - 1;
           cov -= KMER - 1;
-          tneed -= 1;  // (tentative: the junction base agrees by the edge's label)
           st = ST_ENTER;
-        } else if (tent) {  // a differing base, or the read leaves the graph: back to p, general search
-          kmer_pos -= 33u - tneed;
-          cov -= 32u - tneed;
-          mm -= prem ? 1u : 0u;
-          tneed = NO_TENT;
-          st = ST_SEED;
         } else if (kmer_pos >= L || kmer_pos > last_kmer_pos) {
           st = ST_DONE;
-        } else if (prem && ix.mleft && kmer_pos + 3u <= last_kmer_pos &&
+        } else if (NIMBLE_TENT && prem && ix.mleft && kmer_pos + 3u <= last_kmer_pos &&
                    !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(ln.rd, base0 + kmer_pos + 1u, KMER - 1u))) {
           tneed = 32;
           kmer_pos += 1;
