@@ -348,6 +348,13 @@ int nimble_sharded_begin(nimble_comm *, int rank, nimble_ctx *, const nimble_ali
 int nimble_sharded_append(nimble_comm *, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                           const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
 int nimble_sharded_end(nimble_comm *, int rank, uint64_t *n_owned);
+/* A later batch holds a read longer than the call was opened for: every rank widens the records it has kept to the new
+ * max_len (a local device copy, nothing is exchanged and nothing re-read; the key hash covers the bases, not the record
+ * width, so routing stands) -- between two appends, on every rank with the same value, never smaller than before. */
+int nimble_sharded_grow(nimble_comm *, int rank, uint32_t max_len);
+/* Gives the open sharded call up on this rank: the records kept so far are dropped, no kernel is launched, the context is
+ * free for the next begin.  (Local: the other ranks abort or end for themselves.) */
+int nimble_sharded_abort(nimble_comm *, int rank);
 
 #ifdef __cplusplus
 }

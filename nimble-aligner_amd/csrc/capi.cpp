@@ -38,6 +38,11 @@ int fail(int code, const std::string &msg) {
       return fail(NIMBLE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
   } while (0)
 
+// HIP keeps the last error of ANY earlier call of the process (torch, RCCL, another library) until somebody reads it:
+// every entry point that launches reads it away first, so that the check behind its own launches reports its own errors
+// only (round 2: a use-after-free in one test surfaced as "invalid device ordinal" in the next test's first call).
+#define DRAIN_STALE_HIP_ERROR() (void)hipGetLastError()
+
 uint64_t env_u64(const char *name, uint64_t dflt) {
   const char *v = getenv(name);
   if (!v || !*v) return dflt;
@@ -432,7 +437,10 @@ int enqueue_head(nimble_ctx *c) {
   }
   if (c->dedup_clean_slots < c->dslots) HIPCHK(hipMemsetAsync(c->b_dedup.p, 0, c->dslots * 8, s));
   c->dedup_clean_slots = c->defer.active ? c->dslots : 0;  // a deferred call never touches its own table
-  launch_clear_call(s, cb);  // histogram table, state words, hot-key set
+  // histogram table, state words, hot-key set -- and the input-error latch of k_pack, unless the keys of this call were
+  // packed before it (nimble_pack ... nimble_call_packed / nimble_call_records): a latch left by an earlier call whose
+  // results nobody fetched must not fail this one
+  launch_clear_call(s, cb, !c->skip_pack);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[0], s));
   return NIMBLE_OK;
@@ -938,6 +946,7 @@ int nimble_ctx_set_option(nimble_ctx *c, int option, int64_t value) {
 }
 
 int nimble_ctx_synchronize(nimble_ctx *c) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
   HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1142,6 +1151,7 @@ static int start_call(nimble_ctx *c) {
 
 int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
                 const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call: NULL argument");
   int rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
   if (rc) return rc;
@@ -1159,6 +1169,7 @@ int nimble_call(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
 int nimble_call_words(nimble_ctx *c, const nimble_align_params *p, const uint64_t *r1_words, const uint32_t *r1_len,
                       uint32_t r1_stride, const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t n,
                       uint32_t max_len, int mem) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call_words: NULL argument");
   if (mem == NIMBLE_MEM_HOST_PINNED) mem = NIMBLE_MEM_HOST;
   if (mem != NIMBLE_MEM_HOST && mem != NIMBLE_MEM_DEVICE) return fail(NIMBLE_E_INVALID, "nimble_call_words: bad mem");
@@ -1213,6 +1224,7 @@ int nimble_call_words(nimble_ctx *c, const nimble_align_params *p, const uint64_
 int nimble_call_ex(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
                    const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                    const nimble_call_extra *ex) {
+  DRAIN_STALE_HIP_ERROR();
   if (!ex) return nimble_call(c, p, r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
   if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_call_ex: NULL argument");
   int rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
@@ -1294,6 +1306,7 @@ uint32_t nimble_key_words(uint32_t max_len, int paired) { return (max_len * (pai
 int nimble_pack(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, const uint64_t *r1_off,
                 const uint8_t *r2, const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, uint32_t max_len, int mem,
                 const nimble_packed *out) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p || !out) return fail(NIMBLE_E_INVALID, "nimble_pack: NULL argument");
   if (!out->keys || !out->hash || !out->len[0] || !out->pre[0] || (r2 && (!out->len[1] || !out->pre[1])))
     return fail(NIMBLE_E_INVALID, "nimble_pack: output arrays missing");
@@ -1304,6 +1317,7 @@ int nimble_pack(nimble_ctx *c, const nimble_align_params *p, const uint8_t *r1, 
   if (rc) return rc;
   rc = setup_call(c, p, n, r2 != nullptr, max_len, out);
   if (rc) return rc;
+  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 14, 0, 8, c->stream));  // (the latch is this pack's from here on)
   launch_pack(c->stream, c->in_r[0], c->in_off[0], c->in_r[1], c->in_off[1], c->in_fixed_len, c->in_max_len,
               c->prm.min_read_length, c->b_plog.as<double>(), c->plog_max_len, c->cb);
   HIPCHK(hipGetLastError());
@@ -1328,6 +1342,7 @@ static void packed_view(CallBuffers &v, const nimble_packed *pk, uint64_t n) {
 int nimble_route_counts(nimble_ctx *c, uint64_t *counts);
 int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uint32_t world, uint64_t *records,
                          uint64_t *counts) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !in || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_route_records: NULL argument");
   if (world == 0 || world > 256) return fail(NIMBLE_E_INVALID, "nimble_route_records: world must be 1..256");
   if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0] || (in->paired && (!in->len[1] || !in->pre[1]))))
@@ -1362,6 +1377,7 @@ int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uin
 }
 
 int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, const nimble_packed *out) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !out || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_unpack_records: NULL argument");
   if (n && (!out->keys || !out->hash || !out->len[0] || !out->pre[0] || (out->paired && (!out->len[1] || !out->pre[1]))))
     return fail(NIMBLE_E_INVALID, "nimble_unpack_records: packed arrays missing");
@@ -1375,6 +1391,7 @@ int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, co
 
 int nimble_call_records(nimble_ctx *c, const nimble_align_params *p, const uint64_t *records, uint64_t n,
                         uint32_t max_len, int paired) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p || (n && !records)) return fail(NIMBLE_E_INVALID, "nimble_call_records: NULL argument");
   if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_call_records: more than 2^32 reads in one call");
   if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_call_records: bad max_len");
@@ -1409,6 +1426,7 @@ int nimble_ctx_defer_dedup(nimble_ctx *c, uint32_t world, uint64_t *records, uin
 }
 
 int nimble_route_counts(nimble_ctx *c, uint64_t *counts) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !counts) return fail(NIMBLE_E_INVALID, "nimble_route_counts: NULL argument");
   if (c->defer.counts_world == 0) return fail(NIMBLE_E_INVALID, "nimble_route_counts: nothing was routed");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -1423,6 +1441,7 @@ int nimble_route_counts(nimble_ctx *c, uint64_t *counts) {
 }
 
 int nimble_dedup_records(nimble_ctx *c, const uint64_t *records, uint64_t n, uint32_t key_words, uint8_t *verdict) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || (n && (!records || !verdict))) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: NULL argument");
   if (n >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: more than 2^32 records");
   if (key_words == 0) return fail(NIMBLE_E_INVALID, "nimble_dedup_records: key_words is 0");
@@ -1440,6 +1459,7 @@ int nimble_dedup_records(nimble_ctx *c, const uint64_t *records, uint64_t n, uin
 }
 
 int nimble_count_verdicts(nimble_ctx *c, const uint8_t *verdict) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: NULL context");
   if (!c->defer.active || c->finished)
     return fail(NIMBLE_E_INVALID, "nimble_count_verdicts: no call with deferred dedup in flight");
@@ -1453,6 +1473,7 @@ int nimble_count_verdicts(nimble_ctx *c, const uint8_t *verdict) {
 
 int nimble_call_packed(nimble_ctx *c, const nimble_align_params *p, const nimble_packed *in, uint64_t n,
                        uint32_t max_len) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p || !in) return fail(NIMBLE_E_INVALID, "nimble_call_packed: NULL argument");
   if (n && (!in->keys || !in->hash || !in->len[0] || !in->pre[0]))
     return fail(NIMBLE_E_INVALID, "nimble_call_packed: packed arrays missing");
@@ -1540,6 +1561,7 @@ static int stream_grow(nimble_ctx *c, uint64_t newcap) {
 
 int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired, uint32_t max_len,
                         uint64_t capacity_hint) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !p) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: NULL argument");
   if (c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: a streamed call is already open");
   if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_stream_begin: bad max_len");
@@ -1565,6 +1587,7 @@ int nimble_stream_begin(nimble_ctx *c, const nimble_align_params *p, int paired,
   HIPCHK(hipMemcpyAsync(c->p_dyn, c->ix->b_dyn_state.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   c->defer.active = false;
   c->defer.world = 0;
+  c->skip_pack = false;  // (the appends pack: the head clears the input-error latch)
   rc = enqueue_head(c);
   if (rc) return rc;
   c->streaming = true;
@@ -1614,6 +1637,7 @@ static int stream_flush_align(nimble_ctx *c, bool force) {
 
 int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                          const uint64_t *r2_off, uint64_t m, uint32_t fixed_len, int mem) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_append: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_append: no streamed call is open");
   if ((r2 != nullptr) != (c->cb.paired != 0))
@@ -1688,6 +1712,7 @@ int nimble_stream_append(nimble_ctx *c, const uint8_t *r1, const uint64_t *r1_of
 
 int nimble_stream_append_packed(nimble_ctx *c, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
                                 const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t m) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_append_packed: no streamed call is open");
   const bool paired = c->cb.paired != 0;
@@ -1745,6 +1770,7 @@ int nimble_stream_append_packed(nimble_ctx *c, const uint64_t *r1_words, const u
 }
 
 int nimble_stream_end(nimble_ctx *c) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "nimble_stream_end: NULL context");
   if (!c->streaming) return fail(NIMBLE_E_INVALID, "nimble_stream_end: no streamed call is open");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -1800,6 +1826,7 @@ static int finish_count_stage(nimble_ctx *c) { return finish_call(c); }
 
 int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count, uint64_t cap,
                      uint64_t *n_entries) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !n_entries) return fail(NIMBLE_E_INVALID, "nimble_histogram: NULL argument");
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram: no call has been made on this context");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -1818,6 +1845,7 @@ int nimble_histogram(nimble_ctx *c, uint32_t *class_r1, uint32_t *class_r2, uint
 
 int nimble_histogram_seg(nimble_ctx *c, uint32_t *segment, uint32_t *class_r1, uint32_t *class_r2, uint64_t *count,
                          uint32_t *representative, uint64_t cap, uint64_t *n_entries) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !n_entries) return fail(NIMBLE_E_INVALID, "nimble_histogram_seg: NULL argument");
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram_seg: no call has been made on this context");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -1836,6 +1864,7 @@ int nimble_histogram_seg(nimble_ctx *c, uint32_t *segment, uint32_t *class_r1, u
 }
 
 int nimble_read_align_len(nimble_ctx *c, int mate, uint32_t *align_len, uint64_t n) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !align_len) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: NULL argument");
   if (!c->called || n != c->cb.n) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: n does not match the last call");
   if (mate < 0 || mate > 1) return fail(NIMBLE_E_INVALID, "nimble_read_align_len: mate must be 0 or 1");
@@ -1853,6 +1882,7 @@ int nimble_read_align_len(nimble_ctx *c, int mate, uint32_t *align_len, uint64_t
 }
 
 int nimble_histogram_dense_se(nimble_ctx *c, int64_t *counts_dev, uint32_t n_classes) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !counts_dev) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: NULL argument");
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_histogram_dense_se: no call has been made");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -1867,6 +1897,7 @@ int nimble_histogram_dense_se(nimble_ctx *c, int64_t *counts_dev, uint32_t n_cla
 
 int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score, int32_t *mism, uint32_t *cls,
                         uint8_t *counted, uint64_t n) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c) return fail(NIMBLE_E_INVALID, "NULL context");
   if (!c->called || n != c->cb.n) return fail(NIMBLE_E_INVALID, "nimble_read_records: n does not match the last call");
   if (mate < 0 || mate > 1) return fail(NIMBLE_E_INVALID, "nimble_read_records: mate must be 0 or 1");
@@ -1914,6 +1945,7 @@ extern "C" int nimble_debug_state(nimble_ctx *c, uint64_t out[16]) {
 }
 
 int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || !out) return fail(NIMBLE_E_INVALID, "NULL argument");
   if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_call_counters: no call has been made");
   HIPCHK(hipSetDevice(c->ix->device));
@@ -2057,6 +2089,7 @@ int nimble_comm_size(const nimble_comm *c) { return c ? c->n : 0; }
 int nimble_comm_uses_rccl(const nimble_comm *c) { return c && c->rccl ? 1 : 0; }
 
 int nimble_counts_allreduce(nimble_comm *c, int rank, int64_t *counts_dev, uint64_t len, void *stream) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || rank < 0 || rank >= c->n || (len && !counts_dev)) return fail(NIMBLE_E_INVALID, "nimble_counts_allreduce: bad argument");
   HIPCHK(hipSetDevice(c->devices[rank]));
   hipStream_t s = (hipStream_t)stream;
@@ -2100,17 +2133,32 @@ int nimble_counts_allreduce_host(nimble_comm *c, int rank, int64_t *counts, uint
 
 int nimble_records_alltoall(nimble_comm *c, int rank, const uint64_t *send, const uint64_t *send_counts,
                             uint32_t rec_words, uint64_t *recv, uint64_t recv_cap, uint64_t *n_recv, void *stream) {
-  if (!c || rank < 0 || rank >= c->n || !send_counts || !n_recv || rec_words == 0)
-    return fail(NIMBLE_E_INVALID, "nimble_records_alltoall: bad argument");
-  HIPCHK(hipSetDevice(c->devices[rank]));
+  DRAIN_STALE_HIP_ERROR();
+  // Whatever goes wrong on one rank -- a bad argument included -- is carried into agree(), never returned past it: the
+  // other rank threads stand in that barrier, and a rank that left early would leave them there for good.  (Only a call
+  // that cannot name its communicator or rank has nobody to tell.)
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_records_alltoall: bad communicator or rank");
   hipStream_t s = (hipStream_t)stream;
   const int W = c->n;
   int rc = NIMBLE_OK;
-  if (!c->rccl && hipStreamSynchronize(s) != hipSuccess) rc = NIMBLE_E_HIP;  // peers copy straight out of `send`
-  for (int d = 0; d < W; ++d) c->counts[(size_t)rank * W + d] = send_counts[d];
+  std::string why;
+  if (!send_counts || !n_recv || rec_words == 0) {
+    rc = NIMBLE_E_INVALID;
+    why = "nimble_records_alltoall: bad argument";
+  } else if (hipSetDevice(c->devices[rank]) != hipSuccess) {
+    rc = NIMBLE_E_HIP;
+    why = "nimble_records_alltoall: hipSetDevice failed";
+  } else if (!c->rccl && hipStreamSynchronize(s) != hipSuccess) {  // peers copy straight out of `send`
+    rc = NIMBLE_E_HIP;
+    why = "nimble_records_alltoall: the send stream failed";
+  }
+  for (int d = 0; d < W; ++d) c->counts[(size_t)rank * W + d] = rc == NIMBLE_OK ? send_counts[d] : 0;
   c->send_ptr[rank] = send;
-  rc = c->agree(rank, rc);
-  if (rc != NIMBLE_OK) return fail(rc, "nimble_records_alltoall: a rank failed");
+  {
+    const int mine = rc;
+    rc = c->agree(rank, rc);
+    if (rc != NIMBLE_OK) return fail(rc, mine != NIMBLE_OK ? why : "nimble_records_alltoall: a rank failed");
+  }
   uint64_t total = 0;
   for (int src = 0; src < W; ++src) total += c->counts[(size_t)src * W + rank];
   *n_recv = total;
@@ -2119,16 +2167,23 @@ int nimble_records_alltoall(nimble_comm *c, int rank, const uint64_t *send, cons
   if (rc != NIMBLE_OK) return fail(rc, "nimble_records_alltoall: a receive buffer is too small");
   if (c->rccl) {
     uint64_t so = 0, ro = 0;
-    NCCLCHK(ncclGroupStart());
-    for (int peer = 0; peer < W; ++peer) {
+    ncclResult_t nr_ = ncclGroupStart();
+    for (int peer = 0; peer < W && nr_ == ncclSuccess; ++peer) {
       const uint64_t ns = send_counts[peer], nr = c->counts[(size_t)peer * W + rank];
-      if (ns) NCCLCHK(ncclSend(send + so * rec_words, ns * rec_words, ncclUint64, peer, c->comms[rank], s));
-      if (nr) NCCLCHK(ncclRecv(recv + ro * rec_words, nr * rec_words, ncclUint64, peer, c->comms[rank], s));
+      if (ns) nr_ = ncclSend(send + so * rec_words, ns * rec_words, ncclUint64, peer, c->comms[rank], s);
+      if (nr && nr_ == ncclSuccess) nr_ = ncclRecv(recv + ro * rec_words, nr * rec_words, ncclUint64, peer, c->comms[rank], s);
       so += ns;
       ro += nr;
     }
-    NCCLCHK(ncclGroupEnd());
-    c->barrier();  // the count table is free for the next call
+    {
+      const ncclResult_t end_ = ncclGroupEnd();  // (always closed: an open group would swallow the next collective)
+      if (nr_ == ncclSuccess) nr_ = end_;
+    }
+    // the count table is free for the next call -- and every rank learns whether the exchange was issued everywhere
+    rc = c->agree(rank, nr_ == ncclSuccess ? NIMBLE_OK : NIMBLE_E_HIP);
+    if (rc != NIMBLE_OK)
+      return fail(rc, nr_ != ncclSuccess ? std::string("nimble_records_alltoall: ") + ncclGetErrorString(nr_)
+                                          : std::string("nimble_records_alltoall: the exchange failed on another rank"));
     return NIMBLE_OK;
   }
   uint64_t ro = 0;
@@ -2151,6 +2206,7 @@ int nimble_records_alltoall(nimble_comm *c, int rank, const uint64_t *send, cons
 //      reads are, route by key hash, all-to-all, keep what it owns) and finally runs the call over the records it owns.
 int nimble_sharded_begin(nimble_comm *c, int rank, nimble_ctx *ctx, const nimble_align_params *p, int paired,
                          uint32_t max_len) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || rank < 0 || rank >= c->n || !ctx || !p) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: bad argument");
   if (ctx->ix->device != c->devices[rank]) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: the context's index is on another device");
   if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_sharded_begin: bad max_len");
@@ -2167,6 +2223,7 @@ int nimble_sharded_begin(nimble_comm *c, int rank, nimble_ctx *ctx, const nimble
 
 int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                           const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_append: bad argument");
   nimble_comm::Shard &sh = c->shard[rank];
   nimble_ctx *ctx = sh.ctx;
@@ -2247,7 +2304,56 @@ int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uin
   return NIMBLE_OK;
 }
 
+int nimble_sharded_grow(nimble_comm *c, int rank, uint32_t max_len) {
+  DRAIN_STALE_HIP_ERROR();
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_grow: bad argument");
+  nimble_comm::Shard &sh = c->shard[rank];
+  if (!sh.open) return fail(NIMBLE_E_INVALID, "nimble_sharded_grow: no sharded call is open on this rank");
+  if (max_len < sh.max_len || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_sharded_grow: bad max_len");
+  const uint32_t rw_old = sh.rec_words, rw_new = nimble_key_words(max_len, sh.paired) + 2;
+  sh.max_len = max_len;
+  if (rw_new == rw_old) return NIMBLE_OK;
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  hipStream_t s = sh.ctx->stream;
+  if (sh.n_acc) {
+    // rows of rw_old words -> rows of rw_new: the key words keep their place, zero words follow them (the words behind a
+    // key are zero in every record), hash and lengths move to the end of the row
+    DevBuf nb;
+    const uint64_t cap = std::max<uint64_t>(sh.acc_cap, sh.n_acc);
+    int rc = nb.ensure(cap * rw_new * 8, nullptr);
+    if (rc) return rc;
+    const size_t kw_old = (size_t)(rw_old - 2) * 8;
+    hipError_t e = hipMemsetAsync(nb.p, 0, sh.n_acc * rw_new * 8, s);
+    if (e == hipSuccess && kw_old)
+      e = hipMemcpy2DAsync(nb.p, (size_t)rw_new * 8, sh.acc.p, (size_t)rw_old * 8, kw_old, sh.n_acc, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync((uint8_t *)nb.p + (size_t)(rw_new - 2) * 8, (size_t)rw_new * 8, (const uint8_t *)sh.acc.p + kw_old,
+                           (size_t)rw_old * 8, 16, sh.n_acc, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      nb.release();
+      return fail(NIMBLE_E_HIP, std::string("nimble_sharded_grow: ") + hipGetErrorString(e));
+    }
+    sh.acc.release();
+    sh.acc = nb;
+    sh.acc_cap = cap;
+  } else {
+    sh.acc_cap = sh.acc_cap * rw_old / rw_new;  // (the store is empty: only its capacity in records changes)
+  }
+  sh.rec_words = rw_new;
+  return NIMBLE_OK;
+}
+
+int nimble_sharded_abort(nimble_comm *c, int rank) {
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_abort: bad argument");
+  nimble_comm::Shard &sh = c->shard[rank];
+  sh.open = false;
+  sh.n_acc = 0;
+  return NIMBLE_OK;
+}
+
 int nimble_sharded_end(nimble_comm *c, int rank, uint64_t *n_owned) {
+  DRAIN_STALE_HIP_ERROR();
   if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_end: bad argument");
   nimble_comm::Shard &sh = c->shard[rank];
   if (!sh.open) return fail(NIMBLE_E_INVALID, "nimble_sharded_end: no sharded call is open on this rank");

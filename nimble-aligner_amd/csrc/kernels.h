@@ -131,7 +131,7 @@ void launch_dedup_records(hipStream_t s, const uint64_t *rec, uint64_t n, uint32
 void launch_count_verdicts(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, const uint32_t *perm,
                            const uint8_t *verdict);
 void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers &cb);
-void launch_clear_call(hipStream_t s, const CallBuffers &cb);  // histogram table, state words, hot-key set
+void launch_clear_call(hipStream_t s, const CallBuffers &cb, bool clear_latch);  // histogram table, state words, hot-key set
 void launch_publish_state(hipStream_t s, const uint64_t *state, uint64_t *host);  // host: page-locked, 16 words
 void launch_fill_u64(hipStream_t s, uint64_t *p, uint64_t v, uint64_t n);
 

@@ -2588,14 +2588,15 @@ __global__ void k_count_verdicts(nimble_align_params p, CallBuffers cb, const ui
 
 // head of a call: the histogram table, the state words and the hot-key set cleared by one launch (five separate
 // fills cost a launch each)
-__global__ void k_clear_call(CallBuffers cb) {
+__global__ void k_clear_call(CallBuffers cb, int clear_latch) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= cb.hist_mask) {
     cb.hist_keys[i] = HIST_EMPTY;
     cb.hist_cnt[i] = 0;
     if (cb.hist_rep) cb.hist_rep[i] = 0;
   }
-  if (i < 16 && i != 14) cb.state[i] = 0;  // [14] latches input errors found by k_pack until the host has reported them
+  // [14] latches input errors found by k_pack until the host has reported them: it goes with the call whose pack set it
+  if (i < 16 && (i != 14 || clear_latch)) cb.state[i] = 0;
   if (cb.hot && i < HOT_KEYS) cb.hot[i] = 0;
 }
 
@@ -2813,9 +2814,9 @@ void launch_records_unpack(hipStream_t s, const uint64_t *rec, const CallBuffers
   if (cb.n == 0) return;
   hipLaunchKernelGGL(k_records_unpack, dim3(blocks_for(cb.n, 256)), dim3(256), 0, s, rec, cb);
 }
-void launch_clear_call(hipStream_t s, const CallBuffers &cb) {
+void launch_clear_call(hipStream_t s, const CallBuffers &cb, bool clear_latch) {
   const uint64_t items = cb.hist_mask + 1 > HOT_KEYS ? cb.hist_mask + 1 : HOT_KEYS;
-  hipLaunchKernelGGL(k_clear_call, dim3(blocks_for(items, 256)), dim3(256), 0, s, cb);
+  hipLaunchKernelGGL(k_clear_call, dim3(blocks_for(items, 256)), dim3(256), 0, s, cb, clear_latch ? 1 : 0);
 }
 void launch_publish_state(hipStream_t s, const uint64_t *state, uint64_t *host) {
   hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, s, state, host);

@@ -1254,29 +1254,39 @@ void process_sharded(const std::vector<std::string> &input_files,
     nimble_align_params prm;
     align::device_params(aligner_configs.at(li), &prm);
     uint32_t max_len = 0;
-    for (;;) {  // (again from the start if a later batch holds a read longer than the call was opened for)
-      bool too_long = false;
+    {
       Cursor c1(input_files.at(0), false, batch, false);  // (the sharded append takes ASCII)
       std::unique_ptr<Cursor> c2;
       if (paired) c2.reset(new Cursor(input_files[1], true, batch, false));
       bool begun = false;
+      // a failure between begin and end leaves no rank with an open call (the contexts are used again by the next library)
+      struct OpenGuard {
+        nimble_comm *comm;
+        int W;
+        bool armed;
+        ~OpenGuard() {
+          if (armed)
+            for (int r = 0; r < W; ++r) (void)nimble_sharded_abort(comm, r);
+        }
+      } open_guard{comm, W, false};
       for (;;) {
         c1.fill();
         if (paired) c2->fill();
         const uint64_t n = paired ? std::min(c1.avail(), c2->avail()) : c1.avail();
         const uint32_t ml = std::max<uint32_t>(c1.b->data.max_len, paired ? c2->b->data.max_len : 0u);
         if (!begun) {
-          max_len = std::max<uint32_t>(max_len, std::max<uint32_t>(32, (ml + 31u) / 32u * 32u));
+          max_len = std::max<uint32_t>(32, (ml + 31u) / 32u * 32u);
           on_every_rank(W, [&](int r) {
             check_dev(nimble_sharded_begin(comm, r, ranks[(size_t)r]->ctx(), &prm, paired ? 1 : 0, max_len),
                       "nimble_sharded_begin");
           });
           begun = true;
+          open_guard.armed = true;
         }
         if (ml > max_len) {
+          // a later batch holds a longer read: the records every rank has kept are widened in place, nothing is re-read
           max_len = (ml + 31u) / 32u * 32u;
-          too_long = true;
-          break;
+          on_every_rank(W, [&](int r) { check_dev(nimble_sharded_grow(comm, r, max_len), "nimble_sharded_grow"); });
         }
         if (n) {
           const uint64_t *o1 = c1.b->data.offsets.data() + c1.used;
@@ -1300,8 +1310,7 @@ void process_sharded(const std::vector<std::string> &input_files,
         }
         throw Panic(c2->b->error.empty() ? lengths : c2->b->error);
       }
-      if (!too_long) break;
-      on_every_rank(W, [&](int r) { (void)nimble_sharded_end(comm, r, nullptr); });  // close, then start over
+      open_guard.armed = false;
     }
     // every rank: the call over the reads it owns, its rows; the callsets are agreed by content (this is one
     // process: a shared dictionary), the counts summed by an all-reduce of one int64 vector

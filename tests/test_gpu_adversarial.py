@@ -278,3 +278,27 @@ def test_index_freed_before_its_context():
     c2 = nim.Context(idx2)
     c2.call(p, reads.reshape(-1), None, n=1024, fixed_len=150)
     assert c2.histogram() == want
+
+
+def test_a_stale_hip_error_of_another_library_does_not_fail_a_healthy_call():
+    """HIP keeps the last error of any earlier call in the process until somebody reads it.  Provoke one behind the
+    library's back (hipSetDevice(999) straight through the HIP runtime), then make an ordinary call: it must succeed
+    (round 2: the check behind a kernel launch reported whatever error an earlier, unrelated call had left)."""
+    import ctypes as C
+    names, seqs = synth.make_library(12)
+    reads = synth.make_reads(seqs, 4096)
+    import json
+    lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index(0)
+    want = [(f, c) for f, c in lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)]
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert hip is not None, "HIP runtime not loadable"
+    assert hip.hipSetDevice(C.c_int(999)) != 0          # leaves hipErrorInvalidDevice as the process's last error
+    got = [(f, c) for f, c in lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)]
+    assert got == want
+    hip.hipSetDevice(C.c_int(0))

@@ -157,3 +157,79 @@ def test_rccl_communicator_of_one_rank():
     s.synchronize()
     assert n.value == 5 and torch.equal(rv, sd)
     L.nimble_comm_free(comm)
+
+
+def _write_ragged_fastq(path, reads, lens):
+    with open(path, "wb") as f:
+        for i in range(reads.shape[0]):
+            L = int(lens[i])
+            f.write(b"@r%d\n" % i + reads[i, :L].tobytes() + b"\n+\n" + b"I" * L + b"\n")
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_longer_read_in_a_later_batch_widens_the_kept_records(lib_and_reads, devices, monkeypatch):
+    """Batch 1 holds reads of at most 96 bases, later batches reads of up to 150: the sharded call was opened for 96, every
+    rank widens the records it has kept (nimble_sharded_grow) and the run goes on -- the table is the one of a single call
+    over all reads.  (Round 2 re-opened the call here and died on 'the context holds a call in flight'.)"""
+    path, names, seqs, r1, r2, f1, f2, d = lib_and_reads
+    monkeypatch.setenv("NIMBLE_FASTQ_BATCH", "4096")
+    n = 20_000
+    reads = r1[:n]
+    rng = np.random.default_rng(5)
+    lens = np.where(np.arange(n) < 6000, rng.integers(60, 97, size=n), rng.integers(60, 151, size=n))
+    lens[17_000] = 150
+    f = str(d / "ragged.fastq")
+    _write_ragged_fastq(f, reads, lens)
+    # oracle over the ragged reads
+    import json
+    obj = json.load(open(path))
+    cols = [obj[1]["columns"][0], obj[1]["columns"][1], obj[1]["columns"][2], obj[1]["columns"][3]]
+    ref = ora.Reference.from_columns(obj[1]["headers"], cols, obj[0].get("group_on", ""))
+    cfg = ora.config_from_json(obj[0], len(cols[1]), "unstranded")
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    res = ora.call(ora.Index.from_reference(ref), ref, cfg, flat, off)
+    want = "feature\tscore\n" + "".join("\t".join(fe) + "\t%d\n" % c for fe, c in res.rows)
+    lib = nim.Library(path, "unstranded")
+    out = str(d / ("ragged_%d.tsv" % len(devices)))
+    if os.path.exists(out):
+        os.remove(out)
+    nim.fastq_process_sharded([f], lib, devices, out)
+    assert open(out).read() == want
+    # and the single-device pipeline agrees
+    out1 = str(d / "ragged_single.tsv")
+    if os.path.exists(out1):
+        os.remove(out1)
+    nim.fastq_process([f], [nim.Library(path, "unstranded").build_index(0)], [out1])
+    assert open(out1).read() == want
+
+
+def test_a_bad_argument_on_one_rank_reaches_every_rank():
+    """nimble_records_alltoall with a NULL count table on rank 1: rank 1 gets its error, the other ranks get 'a rank
+    failed' -- and nobody is left standing in a barrier (round 2: the bad rank returned before the first agree())."""
+    torch = pytest.importorskip("torch")
+    L = nim.hip_lib()
+    W = 3
+    comm = C.c_void_p()
+    dev = (C.c_int * W)(0, 0, 0)
+    assert L.nimble_comm_create(dev, W, C.byref(comm)) == 0
+    rcs = {}
+
+    def rank(r):
+        s = torch.cuda.Stream()
+        sd = torch.zeros(8 * 7, dtype=torch.int64, device="cuda:0")
+        rv = torch.zeros(64 * 7, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        cnt = np.array([1, 1, 1], dtype=np.uint64)
+        n = C.c_uint64(0)
+        rcs[r] = L.nimble_records_alltoall(comm, r, sd.data_ptr(), None if r == 1 else cnt.ctypes.data, 7, rv.data_ptr(), 64,
+                                           C.byref(n), s.cuda_stream)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting for a peer that failed"
+    assert rcs[1] != 0 and rcs[0] != 0 and rcs[2] != 0
+    L.nimble_comm_free(comm)

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$1; mkdir -p $OUT
 for d in 1 2; do
-timeout -k 5 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/d$d -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --depth $d > $OUT/d$d.log 2>&1
+timeout -k 5 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/d$d -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --e2e-reads 0 --read-sets 1 --depth $d > $OUT/d$d.log 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
