@@ -41,7 +41,7 @@ WORKLOADS = {
                      text="BASELINE.json configs[2]: %(n)d x 150bp single-end reads per GPU vs %(T)d-feature library "
                           "(%(rows)d index rows), basic.json settings (score_percent 0.33, score_threshold 50, "
                           "num_mismatches 0), unstranded"),
-    "configs3": dict(features=1000, family=4, paired=True, reads=5_000_000, total=False,
+    "configs3": dict(features=1000, family=4, paired=True, reads=10_000_000, total=False,
                      text="BASELINE.json configs[3]: %(n)d paired-end 2x150bp read pairs per GPU vs %(T)d-feature library "
                           "(%(rows)d index rows), mismatch.json settings (score_percent 0.08, score_threshold 12, "
                           "num_mismatches 2), unstranded"),
@@ -205,8 +205,8 @@ def main():
     if paired:
         sets = []
         for k in range(n_sets):
-            a, b = synth.make_reads(seqs, n, paired=True, seed=synth.READ_SEED + 7919 * rank + 104729 * k)
-            sets.append((torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)))
+            sets.append(synth.make_pairs_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * rank + 104729 * k,
+                                               device=str(device)))
     else:
         sets = [(synth.make_reads_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * rank + 104729 * k, device=str(device)),
                  None) for k in range(n_sets)]

@@ -354,3 +354,76 @@ def make_family_library(T, F, seed=5, divergence=0.01):
             names.append("G%04d*%03d" % (fam, k))
             seqs.append(ACGT[a].tobytes().decode())
     return names, seqs
+
+
+def make_pairs_torch(seqs, n, L=150, seed=READ_SEED, device="cuda:0", chunk=1 << 20):
+    """The paired recipe of make_reads with torch ops, straight into device memory: fragment length ~ round(N(350, 50^2))
+    clipped to [L, feature length], R1 = fragment[0:L], R2 = revcomp(fragment)[0:L] (or the other way round, by strand),
+    0.5 % substitutions per mate, the same shares of off-target pairs, duplicates of earlier pairs, low-complexity pairs
+    and pairs whose first mate carries N.  Returns two uint8 tensors [n, L].  Deterministic for (n, seed) on a given
+    torch build; not the same stream of numbers as the numpy form."""
+    import torch
+
+    cat_np, off_np = _codes(seqs)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.init()
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed + 2 * n + 1))
+    cat = torch.from_numpy(cat_np).to(dev)
+    off = torch.from_numpy(off_np).to(dev)
+    lens = off[1:] - off[:-1]
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    T = len(seqs)
+    o1 = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    o2 = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    kind = torch.rand(n, generator=g, device=dev)
+    K_ON, K_OFF, K_DUP, K_LOW = 0.75, 0.90, 0.95, 0.98
+    ar = torch.arange(L, device=dev)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        m = hi - lo
+        k = kind[lo:hi]
+        f = torch.randint(0, T, (m,), generator=g, device=dev)
+        flen = lens[f]
+        frag = torch.round(torch.randn(m, generator=g, device=dev, dtype=torch.float64) * 50.0 + 350.0).long()
+        frag = torch.minimum(torch.clamp(frag, min=L), flen)
+        start = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (flen - frag + 1).double()).long()
+        head = cat[(off[f] + start)[:, None] + ar]
+        tail_rc = 3 - cat[(off[f] + start + frag - L)[:, None] + ar].flip(1)
+        strand = torch.rand(m, generator=g, device=dev) < 0.5
+        c1 = torch.where(strand[:, None], tail_rc, head)
+        c2 = torch.where(strand[:, None], head, tail_rc)
+        rnd = []
+        outs = []
+        for c in (c1, c2):
+            mask = torch.rand((m, L), generator=g, device=dev) < 0.005
+            bump = torch.randint(1, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)
+            c = torch.where(mask, (c + bump) % 4, c)
+            r = torch.randint(0, 4, (m, L), generator=g, device=dev, dtype=torch.uint8)
+            offt = (k >= K_ON) & (k < K_OFF)
+            c = torch.where(offt[:, None], r, c)
+            rnd.append(r)
+            outs.append(c)
+        low = (k >= K_DUP) & (k < K_LOW)
+        lowc = rnd[0].clone()
+        lowc[:, : L - 10] = 0
+        a1 = acgt[torch.where(low[:, None], lowc, outs[0]).long()]
+        a2 = acgt[torch.where(low[:, None], lowc, outs[1]).long()]
+        nsel = torch.nonzero(k >= K_LOW).flatten()
+        for rep in range(3):
+            take = nsel if rep == 0 else nsel[torch.rand(nsel.numel(), generator=g, device=dev) < (2.0 / 3.0)]
+            pos = torch.randint(0, L, (take.numel(),), generator=g, device=dev)
+            a1[take, pos] = ord("N")
+        o1[lo:hi] = a1
+        o2[lo:hi] = a2
+    isdup = (kind >= K_OFF) & (kind < K_DUP)
+    dup = torch.nonzero(isdup).flatten()
+    nondup = torch.nonzero(~isdup).flatten()
+    before = torch.searchsorted(nondup, dup)
+    ok = before > 0
+    pick = (torch.rand(dup.numel(), generator=g, device=dev, dtype=torch.float64) * before.clamp(min=1).double()).long()
+    src = nondup[pick]
+    o1[dup[ok]] = o1[src[ok]]
+    o2[dup[ok]] = o2[src[ok]]
+    return o1, o2

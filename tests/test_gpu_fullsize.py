@@ -121,6 +121,58 @@ def test_config3_paired_end_vs_oracle(lib1000, nm):
     assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
 
 
+def test_config3_at_full_size_properties_and_oracle_sample(lib1000):
+    """BASELINE.json configs[3] at its stated size.  "10M paired-end 2x150bp reads" is read as 10 M PAIRS of 2 x 150 bp
+    ("10 M x 2x150 bp PE"), 20 M reads in one call; the settings are mismatch.json's (score_percent
+    0.08, score_threshold 12) with num_mismatches 0, 1 and 2 as tests/mismatch.rs:45 and tests/basic-cases.rs:83,119 run
+    them.  At full size: determinism, conservation, permutation invariance, idempotence under duplication (20 M pairs in
+    one call); against the CPU oracle: a 1 M-pair call at num_mismatches 2 and 250 k-pair calls at 0 and 1, tables
+    bit-exact."""
+    torch = pytest.importorskip("torch")
+    lib, names, seqs = lib1000
+    n = 10_000_000
+    r1, r2 = synth.make_pairs_torch(seqs, n, seed=synth.READ_SEED + 33, device="cuda:0")
+    torch.cuda.synchronize()
+    a, b = r1[:1_000_000].cpu().numpy(), r2[:1_000_000].cpu().numpy()
+    cols = [["s"] * len(names), names, [str(len(s)) for s in seqs], seqs]
+    ref = ora.Reference.from_columns(HEADERS, cols, "")
+    oidx = ora.Index.from_reference(ref)
+
+    def call(x1, x2, m):
+        return lib.score_call(x1, None, x2, None, n=m, fixed_len=150, mem=nim.MEM_DEVICE)
+
+    try:
+        for nm, sample in ((2, 1_000_000), (0, 250_000), (1, 250_000)):
+            over = dict(num_mismatches=nm, score_percent=0.08, score_threshold=12)
+            lib.update_config(**over)
+            base = call(r1, r2, n)
+            assert len(base) > 1000 and all(c > 0 for _, c in base)
+            assert [f for f, _ in base] == sorted(f for f, _ in base)
+            ctx = lib.device_context()
+            ctx.n = n
+            total = sum(c for _, _, c in ctx.histogram())
+            rec = ctx.read_records(0)
+            assert total == int(rec["counted"].sum()) == ctx.counters()["unique_keys"]
+            assert call(r1, r2, n) == base                                   # determinism
+            cfg = ora.config_from_json(synth.library_json(names, seqs)[0], len(names), "unstranded").copy(**over)
+            o = synth.fixed_offsets(sample, 150)
+            exp = ora.call(oidx, ref, cfg, a[:sample].reshape(-1), o, b[:sample].reshape(-1), o, n_threads=16)
+            got = call(r1[:sample].contiguous(), r2[:sample].contiguous(), sample)
+            assert [(f, c) for f, c in got] == [(f, c) for f, c in exp.rows]
+            if nm == 2:
+                perm = torch.randperm(n, device="cuda:0")
+                p1, p2 = r1[perm].contiguous(), r2[perm].contiguous()
+                torch.cuda.synchronize()
+                assert call(p1, p2, n) == base                               # permutation invariance
+                del p1, p2, perm
+                d1, d2 = torch.cat([r1, r1], dim=0).contiguous(), torch.cat([r2, r2], dim=0).contiguous()
+                torch.cuda.synchronize()
+                assert call(d1, d2, 2 * n) == base                           # idempotence: 20 M pairs in one call
+                del d1, d2
+    finally:
+        lib.update_config(num_mismatches=0, score_percent=0.33, score_threshold=50)
+
+
 def test_config4_five_thousand_feature_index():
     # BASELINE.json configs[4] library size (5 k features, 10 k index rows) on one GPU at 300 k reads
     names, seqs = synth.make_library(5000)
