@@ -102,14 +102,14 @@ struct nimble_index {
   hipStream_t intern_last = nullptr;  // the stream ev_intern was last recorded on
   bool released = false;  // nimble_index_free was called while contexts were alive: the last context frees the index
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rowseq, b_runs, b_occ, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
   ~nimble_index() {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_intern) (void)hipEventDestroy(ev_intern);
-    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rowseq, &b_runs, &b_occ, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
+    for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
                       &b_dyn_state})
       b->release();
   }
@@ -723,12 +723,6 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   if (use_l1 && !fi.l1.empty()) up(ix->b_l1, fi.l1);
   static const bool use_mleft = env_u64("NIMBLE_LOCAL_RESEED", 1) != 0;
   if (use_mleft && !fi.mleft.empty()) up(ix->b_mleft, fi.mleft);
-  static const bool use_rows = env_u64("NIMBLE_FAST_WALK", 1) != 0;
-  if (use_rows && use_mleft && !fi.rowseq.empty() && !fi.mleft.empty()) {
-    up(ix->b_rowseq, fi.rowseq);
-    up(ix->b_runs, fi.runs);
-    up(ix->b_occ, fi.node_occ);
-  }
   up(ix->b_rec, fi.node_rec);
   up(ix->b_ledge, fi.node_ledge);
   up(ix->b_unitig, fi.unitig);
@@ -767,9 +761,6 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.l1 = ix->b_l1.p ? ix->b_l1.as<uint32_t>() : nullptr;
   d.mleft = ix->b_mleft.p ? ix->b_mleft.as<uint64_t>() : nullptr;
   d.mleft_log2 = fi.mleft_log2;
-  d.rowseq = ix->b_rowseq.p ? ix->b_rowseq.as<uint64_t>() : nullptr;
-  d.runs = ix->b_runs.as<uint4>();
-  d.node_occ = ix->b_occ.as<uint2>();
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();

@@ -429,73 +429,6 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     for (int k = 0; k < 4; ++k) out.node_rec[nd * 16 + 3 + k] = out.cls_desc[(size_t)c * 4 + k];
   }
   timer.lap("class descriptors");
-  // 8. row space: packed rows, runs, one occurrence per unitig
-  if (n_nodes >= RUN_NODE_MASK) throw std::runtime_error("index build: too many unitigs for the run entries");
-  {
-    std::vector<uint64_t> row_base(n_seqs + 1);
-    uint64_t at = ROWSEQ_PAD;
-    for (uint32_t sq = 0; sq < n_seqs; ++sq) {
-      row_base[sq] = at;
-      at += off[sq + 1] - off[sq];
-    }
-    row_base[n_seqs] = at;
-    if (at + 64 >= (1ULL << 32)) throw std::runtime_error("index build: library exceeds 2^32 bases");
-    out.rowseq.assign((at + 31) / 32 + 4, 0ULL);
-    std::vector<std::vector<uint32_t>> row_runs(n_seqs);
-    parallel_slices(n_seqs, threads, [&](unsigned, size_t lo, size_t hi) {
-      for (size_t sq = lo; sq < hi; ++sq) {
-        const uint8_t *p = seqs + off[sq];
-        const uint64_t len = off[sq + 1] - off[sq];
-        for (uint64_t i = 0; i < len; ++i) {
-          const uint64_t b = encode_base(p[i]), pos = row_base[sq] + i;
-          if (b) __atomic_fetch_or(&out.rowseq[pos >> 5], b << (62 - 2 * (pos & 31)), __ATOMIC_RELAXED);
-        }
-        if (len < KMER) continue;
-        std::vector<uint32_t> &rr = row_runs[sq];
-        uint64_t km = 0;
-        for (uint32_t i = 0; i < KMER - 1; ++i) km = (km << 2) | encode_base(p[i]);
-        uint32_t pn = UINT32_MAX, po = 0;
-        for (uint64_t pos = 0; pos + KMER <= len; ++pos) {
-          km = ((km << 2) | encode_base(p[pos + KMER - 1])) & KMER_MASK;
-          const size_t j = find(km);
-          const uint32_t nd = kmer_node[j], o = kmer_off[j];
-          if (nd != pn || o != po + 1) {
-            const uint32_t col = out.node_rec[(size_t)nd * 16 + 1];
-            rr.push_back((uint32_t)(row_base[sq] + pos));
-            rr.push_back(nd | ((out.node_rec[(size_t)nd * 16] >> 28) << 28));
-            rr.push_back(col);
-            rr.push_back((uint32_t)(row_base[sq] + len));
-            for (int k = 0; k < 4; ++k) rr.push_back(out.cls_desc[(size_t)col * 4 + k]);
-            rr.push_back(o);  // (ninth word, dropped below: the offset the run starts at inside its unitig)
-          }
-          pn = nd;
-          po = o;
-        }
-      }
-    });
-    out.node_occ.assign(n_nodes * 2, 0xFFFFFFFFu);
-    std::vector<uint32_t> occ_o0(n_nodes, 0xFFFFFFFFu);  // offset the chosen occurrence starts at (0 = the whole unitig)
-    out.runs.clear();
-    for (uint32_t sq = 0; sq < n_seqs; ++sq) {
-      const std::vector<uint32_t> &rr = row_runs[sq];
-      if (rr.empty()) continue;
-      for (size_t k = 0; k < rr.size(); k += 9) {
-        const uint32_t nd = rr[k + 1] & RUN_NODE_MASK, e = (uint32_t)(out.runs.size() / 8);
-        if (rr[k + 8] < occ_o0[nd]) {  // the first occurrence that starts nearest the unitig's head
-          occ_o0[nd] = rr[k + 8];
-          out.node_occ[(size_t)nd * 2] = rr[k] - rr[k + 8];  // where the unitig's base 0 lies (mod 2^32)
-          out.node_occ[(size_t)nd * 2 + 1] = e;
-        }
-        out.runs.insert(out.runs.end(), rr.begin() + (long)k, rr.begin() + (long)k + 8);
-      }
-      const uint32_t len = (uint32_t)(off[sq + 1] - off[sq]);
-      const uint32_t endk = (uint32_t)row_base[sq] + len - KMER + 1;
-      const uint32_t end_entry[8] = {endk, RUN_END, 0, (uint32_t)row_base[sq] + len, 0, 0, 0, 0};
-      out.runs.insert(out.runs.end(), end_entry, end_entry + 8);
-    }
-    for (int k = 0; k < 16; ++k) out.runs.push_back(k % 8 == 1 ? RUN_END : 0xFFFFFFF0u);  // two closing entries
-  }
-  timer.lap("row space");
 }
 
 }  // namespace nimble

@@ -17,9 +17,6 @@ constexpr uint32_t KMER = 30;
 constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
 constexpr uint32_t NODE_INLINE_BASES = 64;
-constexpr uint32_t ROWSEQ_PAD = 64;          // bases in front of the first row in FlatIndex::rowseq
-constexpr uint32_t RUN_END = 0x0FFFFFFFu;    // unitig field of the entry that closes a row's runs
-constexpr uint32_t RUN_NODE_MASK = 0x0FFFFFFFu;
 constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
 constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;
 constexpr uint32_t CLS_BITMAP_MAX_ROWS = 1u << 16;  // widest span a static class gets a row bitmap for (8 KiB)  // set in the descriptor's len word when the mask form is valid
@@ -150,17 +147,6 @@ struct FlatIndex {
   // first level of the filter: one bit per value of the 12 shared bases (empty when more than half the bits are set)
   std::vector<uint32_t> l1;
   double l1_density = 0.0;
-  // Row space (the fast walk, kernels.hip fast_walk): the library rows as one 2-bit packed sequence (row s starts at base
-  // row_base[s]; the first row starts at ROWSEQ_PAD so that a word in front of any row can be read), every row as the
-  // list of its RUNS -- maximal stretches of consecutive k-mers that lie in one unitig at consecutive offsets, i.e. what
-  // the walk sees as "enter a unitig, compare to its end, hop" -- and for every unitig one place where it occurs.
-  //   run, 8 x u32: [0] ks = position in rowseq of the run's first k-mer   [1] unitig | right extensions << 28
-  //                 [2] colour   [3] one past the row's last base in rowseq   [4..7] the colour's class descriptor
-  //   a row's runs are followed by one end entry: ks = one past the row's last k-mer, unitig = RUN_END
-  //   node_occ, 2 x u32 per unitig: [0] position in rowseq its base 0 has (would have) in that occurrence  [1] run index
-  std::vector<uint64_t> rowseq;
-  std::vector<uint32_t> runs;
-  std::vector<uint32_t> node_occ;
   // 29-mers with several left flanks among the library k-mers (mleft_maybe): 2^mleft_log2 words
   std::vector<uint64_t> mleft;
   uint32_t mleft_log2 = 0;

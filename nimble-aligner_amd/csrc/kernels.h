@@ -25,10 +25,6 @@ struct DevIndex {
   const uint32_t *l1;       // may be NULL: first level of the filter, one bit per value of the 12 shared bases (2 MiB)
   const uint64_t *mleft;    // may be NULL: 29-mers with several left flanks (flat_index.h mleft_maybe); NULL = no local re-seed
   uint32_t mleft_log2;
-  // row space (flat_index.h): packed rows, runs (2 x uint4 each), one occurrence per unitig; rowseq == NULL: no fast walk
-  const uint64_t *rowseq;
-  const uint4 *runs;
-  const uint2 *node_occ;
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
   const uint64_t *unitig;

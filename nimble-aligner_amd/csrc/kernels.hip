@@ -1440,522 +1440,6 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The fast walk: the same walk in ROW SPACE.
-//
-// A read that comes from the library follows a library row.  Along a row the walk is known in advance: the row's RUNS
-// (flat_index.h) are the unitigs it enters, in order, and the bases it compares are the row's.  So instead of going
-// unitig by unitig -- a dependent gather and a compare per unitig, every lane of the wave at its own pace -- the read is
-// compared with the row in one sweep (a few consecutive words), and the walk is then replayed from the places where
-// they differ:
-//   * no difference up to the next run: the junction base agrees, the walk hops into the next run of the row;
-//   * a difference at a junction base for which the unitig has ANOTHER way out: the read follows another row from
-//     there (an allele of its own) -- the target unitig's occurrence gives the new row, compared from there on;
-//   * a difference anywhere else breaks the walk exactly as in walk() (a mismatch inside a unitig, none at a dead end),
-//     and the next seed is found by walk()'s local rule: the 32 bases behind the break are the row's and the 29-mer behind
-//     it has one left flank only (mleft_maybe), so the k-mer at the break is absent and the one three bases on is the
-//     row's.
-// Whatever does not fit -- differences too close to each other or to the read's end for the local rule, too many of them,
-// a row that ends before the read, a unitig occurrence that is not the one the read lies in -- returns false with nothing
-// counted, and the caller walks the graph (walk()).  The result of a successful fast walk is, visit by visit, the one
-// walk() produces: same unitigs pushed in the same order, same coverage and mismatches, same probe count.
-// ---------------------------------------------------------------------------------------------
-
-// Differences between the lane's read (key bases base0 + [from, L)) and the row bases at qb + [from, L): read positions,
-// ascending, 16 bits each in `mp`; returns their number, 5 = more than four.
-__device__ __forceinline__ uint32_t row_mismatches(const uint64_t *__restrict__ rowseq, const uint64_t *rd, uint32_t base0,
-                                                   uint32_t L, uint32_t qb, uint32_t from, uint64_t &mp) {
-  const uint32_t k0 = base0 + from, k1 = base0 + L;  // key positions [k0, k1)
-  uint32_t cnt = 0;
-  mp = 0;
-  uint32_t w = k0 >> 5;
-  const uint32_t w_end = (k1 + 31u) >> 5;
-  const uint32_t rp = (qb - base0) + 32u * w;  // row position of key position 32 w (at most 31 bases in front of `from`)
-  uint64_t wi = rp >> 5;
-  const uint32_t sh = (rp & 31u) * 2u;
-  uint64_t a = rowseq[wi];
-  for (; w < w_end; ++w) {
-    const uint64_t b = rowseq[++wi];
-    const uint64_t x = rd[w * ALIGN_BLOCK] ^ funnel(a, b, sh);
-    a = b;
-    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;  // key position 32 w + i <-> bit 62 - 2 i
-    const uint32_t lo = k0 > 32u * w ? k0 - 32u * w : 0u;
-    const uint32_t hi = k1 - 32u * w < 32u ? k1 - 32u * w : 32u;
-    if (lo) m &= ~0ULL >> (2u * lo);
-    if (hi < 32u) m &= ~0ULL << (64u - 2u * hi);
-    while (m) {
-      if (cnt == 4u) return 5u;
-      const uint32_t z = (uint32_t)__clzll((long long)m);
-      mp |= (uint64_t)(32u * w + (z >> 1) - base0) << (16u * cnt);
-      ++cnt;
-      m &= ~(0x8000000000000000ULL >> z);
-    }
-  }
-  return cnt;
-}
-
-constexpr uint32_t FAST_MAX_SWITCHES = 6;
-
-__device__ __forceinline__ bool fast_walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed,
-                                          uint32_t node, uint32_t off, uint32_t &coverage, uint32_t &mismatches) {
-  const uint32_t probes0 = ln.probes, nodes0 = ln.nodes;
-  const uint64_t entries0 = ln.entries;
-  ln.n_cols = 0;
-  ln.walk_nodes = 0;
-  const uint32_t last = L - KMER;
-  const uint2 oc0 = ix.node_occ[node];
-  uint32_t qb = oc0.x + off;  // row position of read base 0 (the seed is the read's first k-mer), mod 2^32
-  uint32_t e = oc0.y;
-  uint32_t kpos = 0, from = 0, pos = KMER, cov = KMER, mm = 0, sw = 0;
-  bool ok = false;
-  for (;;) {  // one stretch of the read along one row
-    if (e == 0xFFFFFFFFu) break;
-    uint4 r0 = ix.runs[(size_t)e * 2], r1 = ix.runs[(size_t)e * 2 + 1];
-    uint32_t ks_next = ix.runs[(size_t)e * 2 + 2].x;
-    const uint32_t kabs = qb + kpos;
-    if (!(r0.x <= kabs && kabs < ks_next) || (r0.y & RUN_NODE_MASK) == RUN_END) break;  // not the run of this k-mer
-    if (r0.w - qb < L) break;                                                           // the row ends before the read
-    uint64_t mp;
-    const uint32_t cnt = row_mismatches(ix.rowseq, ln.rd, base0, L, qb, from, mp);
-    if (cnt > 4u || (cnt && (uint32_t)(mp & 0xFFFFu) < pos)) break;
-    uint32_t mi = 0, seen = 0;
-    push_col(ln, r0.z, r1);
-    bool next_row = false;
-    for (;;) {
-      const uint32_t pm = mi < cnt ? (uint32_t)(mp >> (16u * mi)) & 0xFFFFu : 0xFFFFFFFFu;
-      const uint32_t jn = ks_next - qb + (KMER - 1u);  // read position of the base that picks the way out of this run
-      uint32_t stop = pm < jn ? pm : jn;
-      stop = stop < L ? stop : L;
-      cov += stop - pos;
-      pos = stop;
-      if (pos >= L) {
-        ok = true;
-        break;
-      }
-      if (pos == jn && pm != jn) {  // the junction base is the row's: into the row's next run
-        ++e;
-        r0 = ix.runs[(size_t)e * 2];
-        r1 = ix.runs[(size_t)e * 2 + 1];
-        ks_next = ix.runs[(size_t)e * 2 + 2].x;
-        push_col(ln, r0.z, r1);
-        seen = 0;
-        cov += 1;
-        pos += 1;
-        continue;
-      }
-      ++mi;  // the read differs from the row at pos
-      if (pos == jn) {
-        const uint32_t b = lds_base(ln.rd, base0 + pos);
-        if (((r0.y >> 28) >> b) & 1u) {  // the unitig has a way out for the read's base: the read follows another row
-          if (++sw > FAST_MAX_SWITCHES) break;
-          const uint4 re = ix.node_rec[(size_t)(r0.y & RUN_NODE_MASK) * 4 + 2];
-          const uint2 oc = ix.node_occ[sel4(re, b)];
-          kpos = pos - (KMER - 1u);  // the target unitig's first k-mer ends with this base
-          qb = oc.x - kpos;
-          e = oc.y;
-          cov += 1;
-          pos += 1;
-          from = pos;
-          next_row = true;
-          break;
-        }
-        // a dead end: nothing is counted, the seed search starts at pos
-      } else {
-        mm += 1;
-        if (seen < allowed) {  // accepted within this unitig's budget
-          seen += 1;
-          cov += 1;
-          pos += 1;
-          continue;
-        }
-      }
-      // the walk broke at pos: the next seed by the local rule, or back to the graph
-      if (pos > last) {
-        ok = true;
-        break;
-      }
-      const uint32_t nmm = mi < cnt ? (uint32_t)(mp >> (16u * mi)) & 0xFFFFu : 0xFFFFFFFFu;
-      if (nmm < pos + KMER) break;
-      if (mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(ln.rd, base0 + pos + 1u, KMER - 1u))) break;
-      if (pos + 3u > last) {  // only the k-mer at pos was there to examine
-        ln.probes += 1;
-        ok = true;
-        break;
-      }
-      if (nmm < pos + 33u) break;
-      ln.probes += 2;
-      kpos = pos + 3u;
-      bool moved = false;
-      while (ks_next <= qb + kpos) {
-        ++e;
-        ks_next = ix.runs[(size_t)e * 2 + 2].x;
-        moved = true;
-      }
-      if (moved) {
-        r0 = ix.runs[(size_t)e * 2];
-        r1 = ix.runs[(size_t)e * 2 + 1];
-      }
-      push_col(ln, r0.z, r1);
-      seen = 0;
-      cov += KMER;
-      pos = kpos + KMER;
-    }
-    if (!next_row) break;
-  }
-  if (!ok) {
-    ln.probes = probes0;
-    ln.nodes = nodes0;
-    ln.entries = entries0;
-    return false;
-  }
-  coverage = cov;
-  mismatches = mm;
-  return true;
-}
-
-// What pseudoalign and filter_alignment_by_metrics make of a finished walk (shared by both passes of k_align2).
-struct MateOut {
-  uint32_t reason, score, mm, cls, need;
-  uint64_t dhash;
-};
-template <bool WIDE>
-__device__ __forceinline__ MateOut classify(const DevIndex &ix, const Lane &ln, const nimble_align_params &p,
-                                            const CallBuffers &cb, uint32_t Lm, uint32_t cov, uint32_t mis) {
-  MateOut o;
-  o.reason = NIMBLE_R_NONE;
-  o.score = cov;
-  o.mm = mis;
-  o.cls = CLS_NONE;
-  o.need = 0;
-  o.dhash = 0;
-  MaskRes mres;
-  mres.is_mask = false;
-  mres.base = 0;
-  mres.mask = 0;
-  const uint32_t best_col = ln.min_col, best_len = ln.min_len;
-  const bool windowed = WIDE && !ln.all_mask && ln.window_ok;
-  const uint32_t count = windowed ? window_count(ln) : finish_class<WIDE>(ix, ln, o.dhash, nullptr, mres);
-  if (p.discard_nonzero_mismatch && mis != 0) {
-    o.reason = NIMBLE_R_DISCARDED_NONZERO_MISMATCH;
-  } else if ((uint64_t)cov >= p.score_threshold && cov >= cb.min_cov[Lm] && count != 0) {
-    if (p.discard_multiple_matches && count > 1) o.reason = NIMBLE_R_DISCARDED_MULTIPLE_MATCH;
-    else if (mis > p.num_mismatches) o.reason = NIMBLE_R_ABOVE_MISMATCH_THRESHOLD;
-    else {
-      o.reason = NIMBLE_R_SUCCESSFUL_MATCH;
-      if (count == best_len) {
-        o.cls = best_col;
-      } else {
-        o.cls = CLS_PENDING;
-        if (windowed) finish_class<WIDE>(ix, ln, o.dhash, nullptr, mres);
-        if (mres.is_mask || windowed) {
-          const uint32_t tag = intern_tag(o.dhash);
-          uint64_t pos = o.dhash & ix.intern_mask;
-          for (;;) {
-            const uint64_t slot = ix.intern[pos];
-            if (slot == 0) break;
-            const uint32_t id = (uint32_t)slot;
-            if ((uint32_t)(slot >> 32) == tag && id != INTERN_PENDING && id < ix.cls_cap) {
-              const uint4 d = ix.cls_desc[id];
-              if (mres.is_mask) {
-                if (d.x == (count | CLS_MASK_FLAG) && d.y == mres.base && desc_mask(d) == mres.mask) {
-                  o.cls = id;
-                  break;
-                }
-              } else if (d.x == count && window_equals_class(ix, ln, id, count)) {
-                o.cls = id;
-                break;
-              }
-            }
-            pos = (pos + 1) & ix.intern_mask;
-          }
-        }
-        if (o.cls == CLS_PENDING) o.need = count;
-      }
-    }
-  } else {
-    o.reason = NIMBLE_R_SCORE_BELOW_THRESHOLD;
-  }
-  return o;
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_align2: the align stage in two passes per tile.  Pass 1: every mate whose first k-mer is in the dictionary takes the
-// fast walk (uniform work in full waves).  What is left -- mates that need a seed scan, mates the fast walk handed
-// back -- is packed into the first lanes of the block and walks the graph in pass 2 (walk()); waves without such a lane
-// skip it.  Results of both passes are parked per read in LDS and stored by the next loop head in read order.
-// ---------------------------------------------------------------------------------------------
-template <bool PAIRED, bool COUNTERS, bool WIDE>
-__global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES) void k_align2(DevIndex ix, nimble_align_params p,
-                                                                            CallBuffers cb) {
-  constexpr int want_counters = COUNTERS ? 1 : 0;
-  constexpr int nm = PAIRED ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t kw = cb.key_words;
-  const uint32_t krows = kw + 1u;
-  uint64_t *col = lds64 + tid;
-  // layout: key columns | (WIDE) colour-list columns | parked results [nm + 1][256] | tile slot, wave counts, seeds, perms
-  uint32_t *lc_base = reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK);
-  uint64_t *s_res = reinterpret_cast<uint64_t *>(lc_base + (WIDE ? LDS_COLS * ALIGN_BLOCK : 0));
-  uint8_t *extra = reinterpret_cast<uint8_t *>(s_res + (size_t)(nm + 1) * ALIGN_BLOCK);
-  unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
-  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
-  uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
-  uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
-  Lane ln;
-  ln.rd = col;
-  ln.lc = lc_base + tid;
-  ln.ws_lanes = cb.ws_lanes;
-  ln.ws_rows = cb.ws_rows;
-  ln.ws = cb.ws_cols + ((uint64_t)blockIdx.x * ALIGN_BLOCK + tid);
-  ln.want_counters = want_counters;
-  ln.probes = ln.nodes = 0;
-  ln.entries = 0;
-  ln.overflow = 0;
-  ln.n_cols = ln.last_col = ln.walk_nodes = 0;
-  ln.acc = 0;
-  ln.fbase = ln.min_len = ln.min_col = 0;
-  ln.all_mask = true;
-  ln.keep_list = WIDE;
-  ln.window_ok = false;
-  ln.use_window = WIDE && ix.all_bitmaps != 0;
-  ln.wbase = 0;
-  ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = 0;
-  ln.cls_bits = ix.cls_bits;
-  uint32_t c_seeded = 0, c_pre = 0, c_fast = 0, c_tried = 0;
-  const uint64_t n = cb.n;
-  const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  const uint32_t wv = tid >> 6, lane = tid & 63u;
-  uint64_t prev_tile = ~0ULL;
-  for (;;) {
-    __syncthreads();
-    if (prev_tile != ~0ULL) {  // the finished tile's results, in read order: whole lines per store
-      const uint64_t rp = prev_tile * ALIGN_BLOCK + tid;
-      if (rp < n) {
-        const uint64_t rs = s_res[nm * ALIGN_BLOCK + tid];
-#pragma unroll
-        for (int m = 0; m < nm; ++m) {
-          const uint64_t v = s_res[m * ALIGN_BLOCK + tid];
-          st_stream(&cb.reason[m][rp], (uint8_t)(rs >> (8 * m)));
-          st_stream(&cb.score[m][rp], (uint32_t)(v & 0xFFFFu));
-          st_stream(&cb.mism[m][rp], (uint32_t)((v >> 16) & 0xFFFFu));
-          st_stream(&cb.cls[m][rp], (uint32_t)(v >> 32));
-        }
-      }
-    }
-    if (tid == 0) s_tile = atomicAdd((unsigned long long *)&cb.state[12], 1ULL);
-    __syncthreads();
-    const uint64_t tile = s_tile;
-    if (tile >= n_tiles) break;
-    prev_tile = tile;
-    // ---- own slot: key into LDS column tid, first direct probe of mate 0
-    const uint64_t r_own = tile * ALIGN_BLOCK + tid;
-    uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
-    uint64_t seedv = ~0ULL;
-    if (r_own < n) {
-      const uint32_t k0 = rd_len(cb, 0, r_own);
-      const uint32_t l1 = nm == 2 ? rd_len(cb, 1, r_own) : 0u;
-      const uint32_t nw = (k0 + l1 + 31u) >> 5;
-      const uint32_t l0 = rd_alen(cb, 0, r_own);
-      if (cb.rec) {
-        const uint64_t *row = cb.rec + r_own * cb.rec_words;
-        for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? row[w] : 0ULL;
-      } else {
-        for (uint32_t w = 0; w < kw; ++w)
-          col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
-      }
-      col[kw * ALIGN_BLOCK] = 0ULL;
-      if (rd_pre(cb, 0, r_own) == R_TODO && l0 >= KMER) {
-        uint32_t nd = 0, of = 0;
-        ln.rd = col;
-        if (probe_direct(ix, ln, 0u, 0u, nd, of)) {
-          kind = 1;
-          seedv = u64of(of, nd);
-        } else {
-          kind = 0;
-        }
-      }
-    }
-    // ---- first partition: seeded reads first (pass 1 works on full waves of them), then the rest
-    s_seed[tid] = seedv;
-    {
-      const uint64_t b1 = __ballot(kind == 1);
-      if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(b1);
-      __syncthreads();
-      uint32_t tot1 = 0, pre1 = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < ALIGN_BLOCK / 64; ++w) {
-        const uint32_t c1 = s_cnt[w];
-        if (w < wv) pre1 += c1;
-        tot1 += c1;
-      }
-      const uint64_t below = (1ULL << lane) - 1ULL;
-      const uint32_t r1 = (uint32_t)__popcll(b1 & below);
-      const uint32_t pos = kind == 1 ? pre1 + r1 : tot1 + (wv * 64u - pre1) + (lane - r1);
-      s_perm[pos] = (uint16_t)tid;
-      __syncthreads();
-    }
-    // ---- pass 1 (fast walk) and pass 2 (graph walk of what is left)
-    uint32_t n_todo = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1) {
-        // second partition over the parked to-do marks: reads without a seed for mate 0 first (their waves scan), then
-        // the reads the fast walk handed back
-        const uint64_t meta = s_res[nm * ALIGN_BLOCK + tid];
-        const uint32_t td = (uint32_t)(meta >> 56);
-        const bool scan = td != 0 && s_seed[tid] == ~0ULL;
-        const bool back = td != 0 && !scan;
-        const uint64_t b0 = __ballot(scan), b1 = __ballot(back);
-        if (lane == 0) {
-          s_cnt[wv * 2] = (uint32_t)__popcll(b0);
-          s_cnt[wv * 2 + 1] = (uint32_t)__popcll(b1);
-        }
-        __syncthreads();
-        uint32_t tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < ALIGN_BLOCK / 64; ++w) {
-          const uint32_t c0 = s_cnt[w * 2], c1 = s_cnt[w * 2 + 1];
-          if (w < wv) { pre0 += c0; pre1 += c1; }
-          tot0 += c0;
-          tot1 += c1;
-        }
-        const uint64_t below = (1ULL << lane) - 1ULL;
-        if (scan) s_perm[pre0 + (uint32_t)__popcll(b0 & below)] = (uint16_t)tid;
-        if (back) s_perm[tot0 + pre1 + (uint32_t)__popcll(b1 & below)] = (uint16_t)tid;
-        n_todo = tot0 + tot1;
-        __syncthreads();
-        if (wv * 64u >= n_todo) break;  // (uniform per wave) nothing left for this wave
-      }
-      const bool has = pass == 0 || tid < n_todo;
-      const uint32_t slot = has ? s_perm[tid] : 0u;
-      const uint64_t r = tile * ALIGN_BLOCK + slot;
-      const bool active = has && r < n;
-      ln.rd = lds64 + slot;
-      const uint64_t pre_seed = s_seed[slot];
-      uint32_t L[2] = {0, 0};
-      uint32_t mate1_at = 0;
-      uint32_t todo_in = 0;
-      if (active) {
-        L[0] = rd_alen(cb, 0, r);
-        if (nm == 2) {
-          L[1] = rd_alen(cb, 1, r);
-          mate1_at = rd_len(cb, 0, r);
-        }
-        if (pass == 1) todo_in = (uint32_t)(s_res[nm * ALIGN_BLOCK + slot] >> 56);
-      }
-      uint32_t todo_out = 0;
-      // parked per read: reasons (a byte per mate), bit 48 = some mate has walked (counted once per read), to-do marks on top
-      uint64_t reasons = pass == 1 && active ? s_res[nm * ALIGN_BLOCK + slot] & 0x00FFFFFFFFFFFFFFULL : 0ULL;
-      bool any_walk = false;
-      for (int m = 0; m < nm; ++m) {
-        MateOut o;
-        o.reason = NIMBLE_R_NONE;
-        o.score = o.mm = o.need = 0;
-        o.cls = CLS_NONE;
-        o.dhash = 0;
-        bool final_m = false;
-        if (active && (pass == 0 || ((todo_in >> m) & 1u))) {
-          const uint32_t pre = rd_pre(cb, m, r);
-          const uint32_t b0 = m ? mate1_at : 0u;
-          if (pre != R_TODO) {
-            o.reason = pre;
-            final_m = true;
-            if (m == 0) c_pre++;
-          } else {
-            uint32_t cov = 0, mis = 0;
-            bool some = false, walked = false;
-            if (pass == 0) {
-              uint32_t nd = 0, of = 0;
-              bool have = false;
-              if (m == 0) {
-                have = pre_seed != ~0ULL;
-                nd = (uint32_t)(pre_seed >> 32);
-                of = (uint32_t)pre_seed;
-              } else if (L[m] >= KMER) {
-                have = probe_direct(ix, ln, b0, 0u, nd, of);
-                if (!have) ln.probes--;  // (pass 2 makes this probe again, and counts it)
-              }
-              if (have) {
-                c_tried++;
-                if (ix.rowseq && fast_walk(ix, ln, b0, L[m], p.num_mismatches, nd, of, cov, mis)) {
-                  some = walked = true;
-                  c_fast++;
-                } else if (m != 0) {
-                  ln.probes--;
-                }
-              }
-            } else {
-              const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
-              some = walk(ix, ln, b0, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed);
-              walked = true;
-            }
-            if (walked) {
-              final_m = true;
-              if (!some) {
-                o.reason = NIMBLE_R_NO_MATCH;
-              } else {
-                any_walk = true;
-                o = classify<WIDE>(ix, ln, p, cb, L[m], cov, mis);
-              }
-            } else {
-              todo_out |= 1u << m;
-            }
-          }
-        }
-        // wave-aggregated allocation of scratch space for classes that need interning (convergent point)
-        uint32_t total;
-        const uint32_t ofs = wave_excl_scan(o.need, total);
-        unsigned long long base = 0;
-        if (total) {
-          if (lane == 0) base = atomicAdd((unsigned long long *)&cb.state[8], (unsigned long long)total);
-          base = __shfl(base, 0, 64);
-        }
-        if (o.need) {
-          if (base + ofs + o.need <= (unsigned long long)cb.scratch_cap) {
-            uint64_t hh;
-            MaskRes m2;
-            finish_class<WIDE>(ix, ln, hh, cb.scratch + base + ofs, m2);
-            cb.dyn_off[m][r] = (uint32_t)base + ofs;
-            cb.dyn_len[m][r] = o.need;
-            cb.dyn_hash[m][r] = o.dhash;
-          } else {
-            atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_SCRATCH);
-            o.cls = CLS_NONE;
-          }
-        }
-        if (final_m) {
-          s_res[m * ALIGN_BLOCK + slot] = (uint64_t)o.score | ((uint64_t)o.mm << 16) | ((uint64_t)o.cls << 32);
-          reasons = (reasons & ~(0xFFULL << (8 * m))) | ((uint64_t)o.reason << (8 * m));
-        }
-      }
-      if (any_walk && !((reasons >> 48) & 1ULL)) {
-        c_seeded++;
-        reasons |= 1ULL << 48;
-      }
-      if (has) s_res[nm * ALIGN_BLOCK + slot] = reasons | ((uint64_t)todo_out << 56);
-      if (pass == 0) __syncthreads();  // the to-do marks are complete
-    }
-  }
-  if (ln.overflow) atomicOr((unsigned long long *)&cb.state[10], (unsigned long long)ERR_SCRATCH);
-  if (want_counters) {
-    uint64_t v2 = wave_sum64(ln.probes), v3 = wave_sum64(ln.nodes), v4 = wave_sum64(ln.entries);
-    uint64_t v5 = wave_sum64(c_seeded), v6 = wave_sum64(c_pre);
-    if (lane == 0) {
-      atomicAdd((unsigned long long *)&cb.state[2], (unsigned long long)v2);
-      atomicAdd((unsigned long long *)&cb.state[3], (unsigned long long)v3);
-      atomicAdd((unsigned long long *)&cb.state[4], (unsigned long long)v4);
-      atomicAdd((unsigned long long *)&cb.state[5], (unsigned long long)v5);
-      atomicAdd((unsigned long long *)&cb.state[6], (unsigned long long)v6);
-    }
-    // (development: how many mates the fast walk took / was offered; nimble_debug_state)
-    const uint64_t v7 = wave_sum64(c_fast), v1 = wave_sum64(c_tried);
-    if (lane == 0) {
-      atomicAdd((unsigned long long *)&cb.state[7], (unsigned long long)v7);
-      atomicAdd((unsigned long long *)&cb.state[1], (unsigned long long)v1);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // class interning: content-addressed table {tag | class id}; claims and verification are split by a
 // kernel boundary so that no lane ever waits on another lane.
 // ---------------------------------------------------------------------------------------------
@@ -2670,13 +2154,13 @@ static int resident_blocks(const void *fn, size_t lds, int *cus_out) {
   return per_cu;
 }
 
-static const void *align_kernel(bool v2, bool paired, bool counters, bool wide) {
+static const void *align_kernel(bool paired, bool counters, bool wide) {
 #define NIMBLE_PICK(K) \
   (paired ? (counters ? (wide ? (const void *)K<true, true, true> : (const void *)K<true, true, false>)    \
                       : (wide ? (const void *)K<true, false, true> : (const void *)K<true, false, false>)) \
           : (counters ? (wide ? (const void *)K<false, true, true> : (const void *)K<false, true, false>)  \
                       : (wide ? (const void *)K<false, false, true> : (const void *)K<false, false, false>)))
-  return v2 ? NIMBLE_PICK(k_align2) : NIMBLE_PICK(k_align);
+  return NIMBLE_PICK(k_align);
 #undef NIMBLE_PICK
 }
 
@@ -2685,22 +2169,11 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   if (cb.n == 0) return;
   uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
   const bool wide = ix.all_local == 0;
-  // NIMBLE_ALIGN_V2=0: the one-pass kernel (every mate walks the graph); default: fast walk in row space first
-  static const bool v2 = getenv("NIMBLE_ALIGN_V2") ? atoi(getenv("NIMBLE_ALIGN_V2")) != 0 : false;
   const uint32_t nm = cb.paired ? 2u : 1u;
-  size_t lds = 0;
-  bool use_v2 = v2 && ix.rowseq != nullptr;
-  if (use_v2) {
-    lds = (size_t)(cb.key_words + 1) * ALIGN_BLOCK * 8 + (wide ? (size_t)LDS_COLS * ALIGN_BLOCK * 4 : 0) +
-          (size_t)(nm + 1) * ALIGN_BLOCK * 8 + ALIGN_LDS_EXTRA;
-    if (lds > 160 * 1024) use_v2 = false;  // (the longest reads: the parked results no longer fit beside the columns)
-  }
-  if (!use_v2) {
-    const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
-    const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
-    lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
-  }
-  const void *fn = align_kernel(use_v2, cb.paired != 0, want_counters != 0, wide);
+  const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
+  const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
+  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
+  const void *fn = align_kernel(cb.paired != 0, want_counters != 0, wide);
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter.  Residency and the opt-in to more dynamic LDS than the
   // default limit (long reads) are per device and per kernel: rank threads of a sharded call launch concurrently.

@@ -44,15 +44,7 @@ for tag, mix, subst in CASES:
         t = ctx.timing()
         if rep == 0:
             c = ctx.counters() if hasattr(ctx, "counters") else {}
-            try:
-                import ctypes as C
-                st = (C.c_uint64 * 16)()
-                nim.hip_lib().nimble_debug_state.argtypes = [C.c_void_p, C.c_void_p]
-                if nim.hip_lib().nimble_debug_state(ctx.h, st) == 0:
-                    c["fast"] = "%d/%d" % (st[7], st[1])
-            except Exception as ex:
-                c["fast"] = str(ex)
         else:
             best = t["align"] if best is None else min(best, t["align"])
-    print("%-34s k_align %.3f ms   %s" % (tag, best, {k: c[k] for k in ("probes", "nodes", "seeded", "fast") if k in c}), flush=True)
+    print("%-34s k_align %.3f ms   %s" % (tag, best, {k: c[k] for k in ("probes", "nodes", "seeded") if k in c}), flush=True)
     del reads
