@@ -120,6 +120,34 @@ def e2e_fastq(names, seqs, reads_np, n_plain, n_gz):
     return out
 
 
+def native_leg(nim, synth, torch, lib_obj, seqs, devices, n, L, n_sets, warmup, steps):
+    """The multi-GPU step through the C ABI alone (include/nimble_hip.h nimble_comm_* / nimble_steps_*, RCCL inside the
+    device library; include/nimble_host.h nimble_multi_steps): ONE process, one native host thread per device, reads
+    resident on their devices.  The table of the last step must equal ONE call over the union of the ranks' reads of that
+    step (run here on the first device).  Returns a dict for the JSON line."""
+    W = len(devices)
+    libs = [nim.Library(text=json.dumps(lib_obj), strand_filter="unstranded").build_index(d) for d in devices]
+    sets = [[synth.make_reads_torch(seqs, n, L=L, seed=synth.READ_SEED + 7919 * r + 104729 * k, device="cuda:%d" % devices[r])
+             for k in range(n_sets)] for r in range(W)]
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+    ptrs = [[t.data_ptr() for t in rs] for rs in sets]
+    ms, rccl, rows = nim.multi_steps(libs, devices, ptrs, None, n, L, warmup, steps)
+    got = rows.to_list()
+    last = (warmup + steps - 1) % n_sets
+    union = torch.cat([sets[r][last].to("cuda:%d" % devices[0]) for r in range(W)], dim=0).contiguous()
+    torch.cuda.synchronize(devices[0])
+    want = libs[0].score_call_raw(union, None, None, None, n=W * n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE).to_list()
+    del union
+    return {"ms_per_step": ms, "reads_per_s": n * W / (ms / 1000.0), "ranks": W, "devices": list(devices), "rccl": rccl,
+            "rows": len(got),
+            "parity_on_union": ("bit-exact table (%d rows) vs one call over the %d reads of all ranks" % (len(got), W * n))
+            if got == want else "MISMATCH",
+            "note": "one process, one native host thread per rank: pack + route of step i ahead of the call of step i-1, "
+                    "all-to-all of step i (RCCL send/recv inside libnimble_hip.so) beside it, rows + count all-reduce of "
+                    "step i-2 on the host meanwhile; fill and drain of the pipeline inside the timed steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,9 +164,16 @@ def main():
                          "exchange with the previous call)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: run the multi-GPU step (route, all-to-all, reduce over RCCL) even with one rank")
-    ap.add_argument("--form", choices=("sharded", "local"), default=os.environ.get("NIMBLE_MULTI_GPU_FORM", "sharded"),
+    ap.add_argument("--form", choices=("sharded", "local", "native"), default=os.environ.get("NIMBLE_MULTI_GPU_FORM", "sharded"),
                     help="multi-GPU step: 'sharded' moves the packed reads to the key's owner, 'local' aligns where "
-                         "the reads are and moves only keys and verdict bytes")
+                         "the reads are and moves only keys and verdict bytes (both: one process per GPU, torch.distributed "
+                         "for the collectives); 'native' = ONE process, one native host thread per GPU, the C ABI's own "
+                         "RCCL collectives (launch without torch.distributed.run: python bench.py --gpus N --form native)")
+    ap.add_argument("--native", type=int, default=1,
+                    help="multi-GPU under torch.distributed.run: after the torch form, rank 0 also runs the native form over "
+                         "all N devices (0 = skip); the line's value is the faster of the forms that ran and passed parity")
+    ap.add_argument("--native-virtual", type=int, default=0,
+                    help="rehearsal of the native form on ONE GPU: that many ranks share device 0 (device copies instead of RCCL)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="reads timed on the CPU oracle, all host cores (0 = skip); about 11 s at the default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = the host CPUs this process is granted, at most 64)")
@@ -167,10 +202,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    native_only = args.form == "native" and world == 1
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and not native_only:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d "
+                             "(or with --form native as one process)" % (args.gpus, args.gpus))
+    if native_only:
+        args.form = "sharded"  # (the single-GPU part of this run -- counters, roofline -- is the ordinary one)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -182,11 +220,13 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+    ctrl = dist.new_group(backend="gloo") if world > 1 else None  # host-side waits (an RCCL barrier would spin on the GPUs)
 
     wl = WORKLOADS[args.workload]
     L = 150
     T = args.features or wl["features"]
-    n = args.reads or (wl["reads"] // world if wl["total"] else wl["reads"])
+    job_ranks = world if not native_only else max(args.gpus, args.native_virtual, 1)
+    n = args.reads or (wl["reads"] // job_ranks if wl["total"] else wl["reads"])
     paired = wl["paired"]
     if paired and sharded:
         raise SystemExit("bench.py: the paired-end workload is a single-GPU configuration (BASELINE.json configs[3])")
@@ -517,7 +557,30 @@ def main():
         k = max(nd._TIMING.get("steps", 1), 1)
         out["sharded_phase_ms"] = {a: round(b / k, 3) for a, b in nd._TIMING.items() if a != "steps"}
     if rank == 0:
+        # ---- the native form of the multi-GPU step (C ABI collectives, one process): at N > 1 beside the torch form, or
+        # alone (python bench.py --gpus N --form native); never for the paired workload (a single-GPU configuration)
+        want_native = not paired and ((native_only and (args.gpus > 1 or args.native_virtual or args.force_sharded)) or
+                                      (world > 1 and args.native))
+        if want_native:
+            devs = [0] * args.native_virtual if args.native_virtual else list(range(args.gpus if native_only else world))
+            try:
+                nat = native_leg(nim, synth, torch, lib_obj, seqs, devs, n, L, n_sets, max(args.warmup, 3), args.steps)
+            except Exception as ex:  # the line of the torch form must not die with the second form
+                nat = {"error": str(ex)[:400]}
+            out["native"] = nat
+            ok = "error" not in nat and nat.get("parity_on_union", "").startswith("bit-exact")
+            if ok and (native_only or nat["reads_per_s"] > out["value"]):
+                out["torch_form"] = None if native_only else {"value": out["value"], "ms_per_step": out["ms_per_step"]}
+                out["value"] = nat["reads_per_s"]
+                out["ms_per_step"] = nat["ms_per_step"]
+                out["n_gpus"] = len(devs)
+                out["config"]["parallelism"] = ("ONE process, one native host thread per GPU; packed reads routed by key hash, "
+                                                "all-to-all + count all-reduce over RCCL inside the C ABI (nimble_steps_*); "
+                                                "exchange of step i beside the call of step i-1")
+                out["config"]["reads_per_gpu"] = n
         print(json.dumps(out), flush=True)
+    if ctrl is not None:
+        dist.barrier(group=ctrl)  # the other ranks wait here (on the host) while rank 0 runs the native form
     if sharded:
         dist.destroy_process_group()
 

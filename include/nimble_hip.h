@@ -355,6 +355,20 @@ int nimble_sharded_grow(nimble_comm *, int rank, uint32_t max_len);
 /* Gives the open sharded call up on this rank: the records kept so far are dropped, no kernel is launched, the context is
  * free for the next begin.  (Local: the other ranks abort or end for themselves.) */
 int nimble_sharded_abort(nimble_comm *, int rank);
+/* Successive score::calls over reads spread across the ranks, software-pipelined -- a host that runs one call after the
+ * other (the multi-GPU bench step; the consumer pool of src/process/bam.rs:183-226 seen from the device).  The three
+ * contexts launch on one stream (two call contexts, one for packing).  submit(b) packs and routes batch b, launches the
+ * call of batch b-1 right behind it (the launch stream waits for that batch's exchange, the host does not), waits for the
+ * routing of b alone and starts its exchange on the rank's exchange stream, beside the running call.  *launched names
+ * the context whose call has just been enqueued (NULL for the first submit): read its results (nimble_histogram, ...)
+ * before submitting twice more.  flush launches the call of the last batch; end closes.  Every rank submits in step
+ * (n = 0: no reads this round); an error of one rank is reported to all. */
+int nimble_steps_begin(nimble_comm *, int rank, nimble_ctx *call0, nimble_ctx *call1, nimble_ctx *util,
+                       const nimble_align_params *, int paired, uint32_t max_len);
+int nimble_steps_submit(nimble_comm *, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                        const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem, nimble_ctx **launched);
+int nimble_steps_flush(nimble_comm *, int rank, nimble_ctx **launched);
+int nimble_steps_end(nimble_comm *, int rank);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,15 @@ int nimble_fastq_process(int n_inputs, const char *const *inputs, int n_libs, ni
  * library's index is built on every rank's device for the run. */
 int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble_library *lib, const int *devices,
                                  int n_devices, const char *output);
+/* Successive score::calls over device-resident read sets spread across the GPUs of one node, natively: one host thread per
+ * rank, the pipelined step of include/nimble_hip.h (nimble_steps_*), RCCL inside the device library.  libs[rank]: the
+ * library with its index built on devices[rank] (an ordinal may repeat: ranks sharing a GPU, rehearsal and tests);
+ * r1[rank * n_sets + set] (r2 likewise, or NULL): device pointers to n reads of fixed_len bases; step b works on set
+ * b % n_sets; every step ends with the whole job's rows on rank 0.  *ms_per_step: wall time per timed step (pipeline fill
+ * and drain inside); *last: the table of the last step (free with nimble_rows_free). */
+int nimble_multi_steps(nimble_library *const *libs, const int *devices, int world, const uint8_t *const *r1,
+                       const uint8_t *const *r2, int n_sets, uint64_t n, uint32_t fixed_len, int warmup, int steps,
+                       int align_grid_pct, double *ms_per_step, int *used_rccl, nimble_rows **last);
 /* process::bam::process (src/process/bam.rs:45-243): a single BAM file, one gzip-compressed TSV per library.  The reader is
  * this build's own (BGZF + BAM records on zlib, no htslib); the UMI grouping follows src/parse/sorted_bam_reader.rs and
  * src/parse/bam.rs. */

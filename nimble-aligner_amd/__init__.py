@@ -95,6 +95,7 @@ HIP_SYMBOLS = [
     "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl",
     "nimble_counts_allreduce", "nimble_counts_allreduce_host", "nimble_records_alltoall", "nimble_sharded_begin",
     "nimble_sharded_append", "nimble_sharded_end", "nimble_sharded_grow", "nimble_sharded_abort",
+    "nimble_steps_begin", "nimble_steps_submit", "nimble_steps_flush", "nimble_steps_end",
 ]
 
 
@@ -166,6 +167,10 @@ def hip_lib():
         L.nimble_sharded_append.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, i32]
         L.nimble_sharded_end.argtypes = [vp, i32, C.POINTER(u64)]
         L.nimble_sharded_grow.argtypes = [vp, i32, u32]
+        L.nimble_steps_begin.argtypes = [vp, i32, vp, vp, vp, C.POINTER(AlignParams), i32, u32]
+        L.nimble_steps_submit.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, i32, C.POINTER(vp)]
+        L.nimble_steps_flush.argtypes = [vp, i32, C.POINTER(vp)]
+        L.nimble_steps_end.argtypes = [vp, i32]
         L.nimble_sharded_abort.argtypes = [vp, i32]
         _hip = L
     return _hip
@@ -499,7 +504,7 @@ HOST_SYMBOLS = [
     "nimble_library_sequence_idx", "nimble_library_header", "nimble_library_cell", "nimble_library_push_column",
     "nimble_library_build_index", "nimble_library_index", "nimble_library_ctx", "nimble_score_call",
     "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
-    "nimble_write_to_tsv", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
+    "nimble_write_to_tsv", "nimble_multi_steps", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_begin_words", "nimble_score_call_end",
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
@@ -596,6 +601,8 @@ def host_lib():
         L.nimble_rows_get.restype = cp
         L.nimble_fastq_process.argtypes = [i32, pp, i32, C.POINTER(vp), pp]
         L.nimble_fastq_process_sharded.argtypes = [i32, pp, vp, C.POINTER(i32), i32, cp]
+        L.nimble_multi_steps.argtypes = [C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp), C.POINTER(vp), i32, C.c_uint64,
+                                         C.c_uint32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(vp)]
         L.nimble_bam_process.argtypes = [cp, i32, C.POINTER(vp), pp, i32, i32]
         L.nimble_host_bam_dump.argtypes = [cp, i32, cp]
         L.nimble_host_reverse_comp_if_needed.argtypes = [cp, i32, cp, u64]
@@ -1031,6 +1038,23 @@ def fastq_process(input_files, libraries, output_paths):
     arr = (C.c_void_p * len(libraries))(*[l.h for l in libraries])
     _hcheck(host_lib().nimble_fastq_process(len(input_files), _cstrs(input_files), len(libraries), arr,
                                             _cstrs(output_paths)))
+
+
+def multi_steps(libraries, devices, r1_ptrs, r2_ptrs, n, fixed_len, warmup, steps, align_grid_pct=87):
+    """process::multi::run_steps: successive calls over device-resident read sets spread across the GPUs of one node,
+    one native host thread per rank (include/nimble_host.h nimble_multi_steps).  libraries[rank] has its index on
+    devices[rank]; r1_ptrs[rank][set] are device pointers (ints) to n reads of fixed_len bases; r2_ptrs likewise or None.
+    Returns (ms per timed step, over RCCL?, rows of the last step)."""
+    W = len(devices)
+    n_sets = len(r1_ptrs[0])
+    libs = (C.c_void_p * W)(*[l.h for l in libraries])
+    dev = (C.c_int * W)(*devices)
+    a1 = (C.c_void_p * (W * n_sets))(*[p for r in r1_ptrs for p in r])
+    a2 = (C.c_void_p * (W * n_sets))(*[p for r in r2_ptrs for p in r]) if r2_ptrs else None
+    ms, rccl, rows = C.c_double(0.0), C.c_int(0), C.c_void_p()
+    _hcheck(host_lib().nimble_multi_steps(libs, dev, W, a1, a2, n_sets, n, fixed_len, warmup, steps, align_grid_pct,
+                                          C.byref(ms), C.byref(rccl), C.byref(rows)))
+    return ms.value, bool(rccl.value), RowsHandle(rows)
 
 
 def fastq_process_sharded(input_files, library, devices, output_path):

@@ -1996,6 +1996,18 @@ struct nimble_comm {
     DevBuf send, acc, vec;
     uint64_t n_acc = 0, acc_cap = 0;
     bool open = false;
+    // successive calls, software-pipelined (nimble_steps_*)
+    struct Steps {
+      bool open = false;
+      nimble_ctx *call[2] = {nullptr, nullptr}, *util = nullptr;
+      hipStream_t xstream = nullptr;           // the exchange runs here, beside the call of the batch before
+      hipEvent_t ev_routed = nullptr, ev_x[2] = {nullptr, nullptr};
+      DevBuf send[2], recv[2];
+      uint64_t recv_cap[2] = {0, 0}, n_recv[2] = {0, 0};
+      uint64_t *p_counts = nullptr;            // page-locked: per-destination counts [0, W) and the input-error latch [W]
+      uint64_t b = 0;                          // batches submitted
+      bool pending = false;                    // batch b - 1 is exchanged, its call not yet launched
+    } st;
   };
   std::vector<Shard> shard;
   void barrier() {
@@ -2071,6 +2083,15 @@ void nimble_comm_free(nimble_comm *c) {
     c->shard[r].send.release();
     c->shard[r].acc.release();
     c->shard[r].vec.release();
+    nimble_comm::Shard::Steps &st = c->shard[r].st;
+    for (int k = 0; k < 2; ++k) {
+      st.send[k].release();
+      st.recv[k].release();
+      if (st.ev_x[k]) (void)hipEventDestroy(st.ev_x[k]);
+    }
+    if (st.ev_routed) (void)hipEventDestroy(st.ev_routed);
+    if (st.xstream) (void)hipStreamDestroy(st.xstream);
+    if (st.p_counts) (void)hipHostFree(st.p_counts);
   }
   for (ncclComm_t m : c->comms) (void)ncclCommDestroy(m);
   delete c;
@@ -2340,6 +2361,158 @@ int nimble_sharded_abort(nimble_comm *c, int rank) {
   nimble_comm::Shard &sh = c->shard[rank];
   sh.open = false;
   sh.n_acc = 0;
+  return NIMBLE_OK;
+}
+
+// ---- successive score::calls over reads spread across the ranks, software-pipelined.  For batch b of a rank:
+//        P(b)  pack + route by key hash          launch stream (utility context)
+//        X(b)  all-to-all of the routed records  the rank's exchange stream, beside C(b-1)
+//        C(b)  the call over the records the rank received     launch stream, call context b % 2
+//      submit(b) enqueues P(b) and, right behind it, C(b-1) (the launch stream waits for X(b-1)'s event, not the host); the host
+//      waits for the routing of b alone (an event behind P(b)) and issues X(b).  Nothing here waits for a call: the caller reads
+//      the results of the context `launched` names (nimble_histogram ...) whenever it likes -- before it submits twice more.
+int nimble_steps_begin(nimble_comm *c, int rank, nimble_ctx *call0, nimble_ctx *call1, nimble_ctx *util,
+                       const nimble_align_params *p, int paired, uint32_t max_len) {
+  DRAIN_STALE_HIP_ERROR();
+  if (!c || rank < 0 || rank >= c->n || !call0 || !call1 || !util || !p) return fail(NIMBLE_E_INVALID, "nimble_steps_begin: bad argument");
+  if (call0->stream != call1->stream || call0->stream != util->stream)
+    return fail(NIMBLE_E_INVALID, "nimble_steps_begin: the three contexts must launch on one stream");
+  if (call0->ix->device != c->devices[rank]) return fail(NIMBLE_E_INVALID, "nimble_steps_begin: the contexts' index is on another device");
+  if (max_len == 0 || max_len > 65535) return fail(NIMBLE_E_INVALID, "nimble_steps_begin: bad max_len");
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  nimble_comm::Shard &sh = c->shard[rank];
+  nimble_comm::Shard::Steps &st = sh.st;
+  if (st.open) return fail(NIMBLE_E_INVALID, "nimble_steps_begin: already open on this rank");
+  if (!st.xstream) HIPCHK(hipStreamCreateWithFlags(&st.xstream, hipStreamNonBlocking));
+  if (!st.ev_routed) HIPCHK(hipEventCreateWithFlags(&st.ev_routed, hipEventDisableTiming));
+  for (int k = 0; k < 2; ++k)
+    if (!st.ev_x[k]) HIPCHK(hipEventCreateWithFlags(&st.ev_x[k], hipEventDisableTiming));
+  if (!st.p_counts) HIPCHK(hipHostMalloc((void **)&st.p_counts, (size_t)(c->n + 1) * 8, hipHostMallocDefault));
+  st.call[0] = call0;
+  st.call[1] = call1;
+  st.util = util;
+  sh.prm = *p;
+  sh.paired = paired ? 1 : 0;
+  sh.max_len = max_len;
+  sh.rec_words = nimble_key_words(max_len, paired) + 2;
+  st.b = 0;
+  st.pending = false;
+  st.open = true;
+  return NIMBLE_OK;
+}
+
+// launch C(b - 1): the call over what the exchange of batch b - 1 delivered
+static int steps_launch_pending(nimble_comm *c, int rank, nimble_ctx **launched) {
+  nimble_comm::Shard &sh = c->shard[rank];
+  nimble_comm::Shard::Steps &st = sh.st;
+  if (launched) *launched = nullptr;
+  if (!st.pending) return NIMBLE_OK;
+  const int k = (int)((st.b - 1) & 1);
+  nimble_ctx *ctx = st.call[k];
+  if (ctx->called && !ctx->finished)
+    return fail(NIMBLE_E_INVALID, "nimble_steps: the results of the call before last were not fetched (its context is still busy)");
+  HIPCHK(hipStreamWaitEvent(ctx->stream, st.ev_x[k], 0));
+  int rc = nimble_call_records(ctx, &sh.prm, st.recv[k].as<uint64_t>(), st.n_recv[k], sh.max_len, sh.paired);
+  if (rc) return rc;
+  st.pending = false;
+  if (launched) *launched = ctx;
+  return NIMBLE_OK;
+}
+
+int nimble_steps_submit(nimble_comm *c, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                        const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem, nimble_ctx **launched) {
+  DRAIN_STALE_HIP_ERROR();
+  if (launched) *launched = nullptr;
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_steps_submit: bad argument");
+  nimble_comm::Shard &sh = c->shard[rank];
+  nimble_comm::Shard::Steps &st = sh.st;
+  const int W = c->n;
+  const int k = (int)(st.b & 1);
+  nimble_ctx *u = st.util;
+  // (a failure of one rank must not leave the others waiting at a barrier: local errors are carried to the collectives)
+  int rc = st.open ? NIMBLE_OK : fail(NIMBLE_E_INVALID, "nimble_steps_submit: not open on this rank");
+  if (rc == NIMBLE_OK && (r2 != nullptr) != (sh.paired != 0)) rc = fail(NIMBLE_E_INVALID, "nimble_steps_submit: mates given for a single-end call or missing for a paired one");
+  if (rc == NIMBLE_OK && !r1_off && fixed_len > sh.max_len) rc = fail(NIMBLE_E_INVALID, "nimble_steps_submit: a read longer than max_len");
+  if (rc == NIMBLE_OK) rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, sh.max_len, mem);
+  if (rc == NIMBLE_OK && hipSetDevice(c->devices[rank]) != hipSuccess) rc = fail(NIMBLE_E_HIP, "hipSetDevice");
+  const uint32_t rw = sh.rec_words;
+  std::vector<uint64_t> counts(W, 0);
+  // ---- P(b)
+  if (rc == NIMBLE_OK && n) {
+    rc = stage_inputs(u, r1, r1_off, r2, r2_off, n, fixed_len, sh.max_len, mem);
+    if (rc == NIMBLE_OK) rc = setup_call(u, &sh.prm, n, r2 != nullptr, sh.max_len, nullptr);
+    const uint64_t cells = (uint64_t)route_grid() * W;
+    if (rc == NIMBLE_OK) rc = u->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &u->bytes);
+    if (rc == NIMBLE_OK) rc = st.send[k].ensure(std::max<uint64_t>(n * rw * 8, 16), nullptr);
+    if (rc == NIMBLE_OK) {
+      if (hipMemsetAsync((uint64_t *)u->b_state.p + 14, 0, 8, u->stream) != hipSuccess) rc = fail(NIMBLE_E_HIP, "hipMemsetAsync");
+    }
+    if (rc == NIMBLE_OK) {
+      launch_pack(u->stream, u->in_r[0], u->in_off[0], u->in_r[1], u->in_off[1], u->in_fixed_len, u->in_max_len,
+                  u->prm.min_read_length, u->b_plog.as<double>(), u->plog_max_len, u->cb);
+      uint64_t *block_first = u->b_route.as<uint64_t>();
+      uint64_t *totals = block_first + cells;
+      uint32_t *block_counts = reinterpret_cast<uint32_t *>(totals + 256);
+      launch_route(u->stream, u->cb, (uint32_t)W, block_counts, block_first, totals, st.send[k].as<uint64_t>());
+      if (hipMemcpyAsync(st.p_counts, totals, (size_t)W * 8, hipMemcpyDeviceToHost, u->stream) != hipSuccess ||
+          hipMemcpyAsync(st.p_counts + W, (uint64_t *)u->b_state.p + 14, 8, hipMemcpyDeviceToHost, u->stream) != hipSuccess ||
+          hipGetLastError() != hipSuccess)
+        rc = fail(NIMBLE_E_HIP, "nimble_steps_submit: pack / route launch failed");
+    }
+  }
+  if (hipEventRecord(st.ev_routed, u ? u->stream : nullptr) != hipSuccess && rc == NIMBLE_OK) rc = fail(NIMBLE_E_HIP, "hipEventRecord");
+  // ---- C(b - 1) right behind P(b) on the launch stream
+  if (rc == NIMBLE_OK) rc = steps_launch_pending(c, rank, launched);
+  // ---- the host waits for the routing of b alone
+  if (hipEventSynchronize(st.ev_routed) != hipSuccess && rc == NIMBLE_OK) rc = fail(NIMBLE_E_HIP, "nimble_steps_submit: routing failed");
+  if (rc == NIMBLE_OK && n) {
+    if (st.p_counts[W] != 0) rc = fail(NIMBLE_E_INVALID, "offsets not monotone or a read longer than max_len (found on the device)");
+    else std::copy(st.p_counts, st.p_counts + W, counts.begin());
+  }
+  const std::string my_error = rc == NIMBLE_OK ? std::string() : g_err;
+  // ---- room for what the others send (the incoming total is known once everybody has published its counts)
+  for (int d = 0; d < W; ++d) c->counts[(size_t)rank * W + d] = counts[d];
+  int all = c->agree(rank, rc);
+  uint64_t incoming = 0;
+  for (int src = 0; src < W; ++src) incoming += c->counts[(size_t)src * W + rank];
+  c->barrier();
+  if (all != NIMBLE_OK) return rc != NIMBLE_OK ? fail(rc, my_error) : fail(all, "nimble_steps_submit: another rank failed");
+  if (incoming > st.recv_cap[k]) {  // (C(b - 2), the last reader of this buffer, has finished: P(b) stood behind it)
+    const uint64_t cap = std::max<uint64_t>(incoming + incoming / 8, 1u << 16);
+    rc = st.recv[k].ensure(cap * rw * 8, nullptr);
+    if (rc == NIMBLE_OK) st.recv_cap[k] = cap;
+  }
+  all = c->agree(rank, rc);
+  if (all != NIMBLE_OK) return rc != NIMBLE_OK ? rc : fail(all, "nimble_steps_submit: another rank failed");
+  // ---- X(b) beside C(b - 1)
+  uint64_t got = 0;
+  rc = nimble_records_alltoall(c, rank, st.send[k].as<uint64_t>(), counts.data(), rw, st.recv[k].as<uint64_t>(), st.recv_cap[k],
+                               &got, st.xstream);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(st.ev_x[k], st.xstream));
+  st.n_recv[k] = got;
+  st.pending = true;
+  st.b += 1;
+  return NIMBLE_OK;
+}
+
+int nimble_steps_flush(nimble_comm *c, int rank, nimble_ctx **launched) {
+  DRAIN_STALE_HIP_ERROR();
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_steps_flush: bad argument");
+  if (!c->shard[rank].st.open) return fail(NIMBLE_E_INVALID, "nimble_steps_flush: not open on this rank");
+  HIPCHK(hipSetDevice(c->devices[rank]));
+  return steps_launch_pending(c, rank, launched);
+}
+
+int nimble_steps_end(nimble_comm *c, int rank) {
+  if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_steps_end: bad argument");
+  nimble_comm::Shard::Steps &st = c->shard[rank].st;
+  if (st.xstream) {
+    (void)hipSetDevice(c->devices[rank]);
+    (void)hipStreamSynchronize(st.xstream);
+  }
+  st.open = false;
+  st.pending = false;
   return NIMBLE_OK;
 }
 

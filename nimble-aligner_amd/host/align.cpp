@@ -509,6 +509,28 @@ void begin_calls(const ReadBatch &seqs, const ReadBatch *mates, PseudoAligner &i
            "nimble_call");
 }
 
+// A table of (callset, count) as the rows of `index` (light rows: ids into its coercion memo, which learns the callsets it
+// has not produced itself -- the counts of several ranks summed, handed out through rank 0's index).
+CallOutput rows_from_table(PseudoAligner &index, const reference_library::Reference &reference,
+                           const AlignFilterConfig &config, const std::map<std::vector<std::string>, int64_t> &table) {
+  PseudoAligner::CoercionMemo &memo = index.memo_for(reference, config);
+  CallOutput out;
+  out.refs.memo = index.memo_ptr();
+  for (const auto &kv : table) {  // std::map order == Vec<String> order
+    if (kv.second == 0) continue;
+    auto ins = memo.callset_ids.emplace(kv.first, (int32_t)memo.callsets.size());
+    if (ins.second) {
+      memo.callsets.push_back(kv.first);
+      memo.counts.push_back(0);
+      memo.sorted.clear();
+    }
+    out.refs.ids.push_back(ins.first->second);
+    out.refs.counts.push_back((int32_t)kv.second);
+  }
+  if (!index.light_rows()) out.materialize();
+  return out;
+}
+
 CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                      const AlignFilterConfig &config, int slot, bool want_per_read) {
   return finish_calls(n_reads, index, reference, config, want_per_read, std::chrono::steady_clock::now(), slot);

@@ -572,6 +572,41 @@ int nimble_fastq_process_sharded(int n_inputs, const char *const *inputs, nimble
   });
 }
 
+int nimble_multi_steps(nimble_library *const *libs, const int *devices, int world, const uint8_t *const *r1,
+                       const uint8_t *const *r2, int n_sets, uint64_t n, uint32_t fixed_len, int warmup, int steps,
+                       int align_grid_pct, double *ms_per_step, int *used_rccl, nimble_rows **last) {
+  if (last) *last = nullptr;
+  return guarded([&] {
+    if (!libs || !devices || world < 1 || !r1 || n_sets < 1 || !ms_per_step || !last) throw Panic("nimble_multi_steps: bad argument");
+    std::vector<std::unique_ptr<align::PseudoAligner>> idx;
+    // the libraries lend their indices for the run (one per rank, each on its rank's device)
+    for (int r = 0; r < world; ++r) {
+      if (!libs[r] || !libs[r]->index) throw Panic("nimble_multi_steps: a library has no index");
+      idx.push_back(std::move(libs[r]->index));
+    }
+    struct Return {
+      nimble_library *const *libs;
+      std::vector<std::unique_ptr<align::PseudoAligner>> &idx;
+      ~Return() {
+        for (size_t r = 0; r < idx.size(); ++r) libs[r]->index = std::move(idx[r]);
+      }
+    } give_back{libs, idx};
+    std::vector<std::vector<const uint8_t *>> reads((size_t)world), mates;
+    if (r2) mates.resize((size_t)world);
+    for (int r = 0; r < world; ++r)
+      for (int s = 0; s < n_sets; ++s) {
+        reads[(size_t)r].push_back(r1[(size_t)r * n_sets + s]);
+        if (r2) mates[(size_t)r].push_back(r2[(size_t)r * n_sets + s]);
+      }
+    const std::vector<int> dev(devices, devices + world);
+    process::multi::StepsResult res = process::multi::run_steps(idx, libs[0]->ref, libs[0]->cfg, dev, reads, mates, n, fixed_len,
+                                                                warmup, steps, align_grid_pct);
+    *ms_per_step = res.ms_per_step;
+    if (used_rccl) *used_rccl = res.rccl ? 1 : 0;
+    *last = make_rows(std::move(res.last));
+  });
+}
+
 int nimble_write_to_tsv(const nimble_rows *r, const char *path) {
   return guarded([&] {
     align::CallOutput copy;

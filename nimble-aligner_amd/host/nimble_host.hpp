@@ -209,6 +209,10 @@ void begin_calls(const ReadBatch &sequences, const ReadBatch *mate_sequences, Ps
 CallOutput end_calls(uint64_t n_reads, PseudoAligner &index, const reference_library::Reference &reference,
                      const AlignFilterConfig &config, int slot, bool want_per_read = false);
 
+// a summed table (several ranks) as rows of `index`
+CallOutput rows_from_table(PseudoAligner &index, const reference_library::Reference &reference,
+                           const AlignFilterConfig &config, const std::map<std::vector<std::string>, int64_t> &table);
+
 // What the BAM pipeline adds to a call (process/bam.rs:229-290, align.rs:516-552); every field optional.
 struct UmiExtras {
   const uint32_t *segment = nullptr;  // [n] UMI group per read(-pair): one score::call each
@@ -540,6 +544,27 @@ void process_sharded(const std::vector<std::string> &input_files,
                      const std::vector<align::AlignFilterConfig> &aligner_configs,
                      const std::vector<std::string> &output_paths, const std::vector<int> &devices);
 }  // namespace fastq
+
+namespace multi {
+// Successive score::calls over device-resident read sets spread across the GPUs of one node, through the pipelined native
+// step of the C ABI (include/nimble_hip.h nimble_steps_*): one rank = one host thread per device, RCCL inside the
+// library, no torch -- what a host with a consumer pool (src/process/bam.rs:183-226) does call after call, and the
+// multi-GPU step bench.py times (`--form native`).  indices[rank]: the library's index on that rank's device.
+// reads[rank][set] (mates[rank][set], or empty): device pointers to n reads of fixed_len bases each; step b works on set
+// b % n_sets.  Every step ends with the rows of the whole job on rank 0 (callsets agreed by content, counts summed by
+// nimble_counts_allreduce).  Returns the wall milliseconds per timed step (fill and drain of the pipeline inside) and
+// leaves the last step's table in *last.
+struct StepsResult {
+  double ms_per_step = 0.0;
+  align::CallOutput last;
+  bool rccl = false;
+};
+StepsResult run_steps(std::vector<std::unique_ptr<align::PseudoAligner>> &indices,
+                      const reference_library::Reference &reference, const align::AlignFilterConfig &config,
+                      const std::vector<int> &devices, const std::vector<std::vector<const uint8_t *>> &reads,
+                      const std::vector<std::vector<const uint8_t *>> &mates, uint64_t n, uint32_t fixed_len, int warmup,
+                      int steps, int align_grid_pct);
+}  // namespace multi
 }  // namespace process
 
 }  // namespace nimble

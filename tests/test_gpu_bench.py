@@ -34,3 +34,20 @@ def test_bench_workloads_run_and_check_parity(workload, extra):
     if workload == "configs2":
         assert d["packed_input"]["reads_per_s"] > 0
         assert d["e2e_fastq_reads_per_s"] > 0 and d["e2e_fastq_gz_reads_per_s"] > 0
+
+
+@pytest.mark.parametrize("extra", [["--force-sharded"], ["--native-virtual", "3"]])
+def test_bench_native_form_of_the_multi_gpu_step(extra):
+    """`--form native`: the multi-GPU step through the C ABI alone (one process, one native thread per rank) -- over real RCCL
+    with one rank, and with three ranks sharing this box's GPU; the line reports the native figures and its own parity
+    check (the job's table == one call over the union of the ranks' reads)."""
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--form", "native", "--steps", "4", "--warmup", "1",
+                         "--reads", "40000", "--features", "64", "--cpu-sample", "0", "--e2e-reads", "0", "--packed-input", "0"]
+                        + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert cp.returncode == 0, cp.stderr[-800:]
+    d = json.loads(cp.stdout.strip().splitlines()[-1])
+    nat = d["native"]
+    assert "error" not in nat, nat
+    assert nat["parity_on_union"].startswith("bit-exact")
+    assert nat["ranks"] == (3 if "--native-virtual" in extra else 1) and nat["rccl"] == ("--force-sharded" in extra)
+    assert d["value"] == nat["reads_per_s"] and d["ms_per_step"] == nat["ms_per_step"]

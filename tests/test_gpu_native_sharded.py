@@ -233,3 +233,39 @@ def test_a_bad_argument_on_one_rank_reaches_every_rank():
     assert not any(t.is_alive() for t in ts), "a rank is still waiting for a peer that failed"
     assert rcs[1] != 0 and rcs[0] != 0 and rcs[2] != 0
     L.nimble_comm_free(comm)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("paired", [False, True])
+def test_pipelined_native_steps_equal_one_call_over_the_union(lib_and_reads, devices, paired):
+    """nimble_steps_* through process::multi::run_steps (include/nimble_host.h nimble_multi_steps): successive calls over
+    device-resident read sets spread across the ranks, one native thread per rank, pack + route of batch b ahead of the
+    call of b-1, the exchange of b beside it.  The table of the last step is the table of ONE call over the union of the
+    ranks' reads of that step's set -- at world 1 over real RCCL (ncclSend/ncclRecv to oneself), at world 2 and 3 with
+    virtual ranks on this one device.  Read sets differ per step, so a pipeline that mixed batches up would show."""
+    torch = pytest.importorskip("torch")
+    path, names, seqs, r1, r2, f1, f2, d = lib_and_reads
+    W = len(devices)
+    n_sets, n = 3, 6000
+    libs = [nim.Library(path, "unstranded").build_index(0) for _ in range(W)]
+    sets1, sets2, keep = [], [], []
+    for r in range(W):
+        p1, p2 = [], []
+        for s_ in range(n_sets):
+            lo = (r * n_sets + s_) * n
+            a = torch.from_numpy(np.ascontiguousarray(r1[lo:lo + n])).to("cuda:0")
+            b = torch.from_numpy(np.ascontiguousarray(r2[lo:lo + n])).to("cuda:0")
+            keep += [a, b]
+            p1.append(a.data_ptr())
+            p2.append(b.data_ptr())
+        sets1.append(p1)
+        sets2.append(p2)
+    torch.cuda.synchronize()
+    warmup, steps = 2, 5
+    ms, rccl, rows = nim.multi_steps(libs, devices, sets1, sets2 if paired else None, n, 150, warmup, steps)
+    assert rccl == (W == 1) and ms > 0
+    last_set = (warmup + steps - 1) % n_sets
+    sel = np.concatenate([np.arange((r * n_sets + last_set) * n, (r * n_sets + last_set + 1) * n) for r in range(W)])
+    want = oracle_tsv(path, "unstranded", r1[sel], r2[sel] if paired else None)
+    got = "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in rows.to_list())
+    assert got == want
