@@ -25,6 +25,8 @@ CASES = [
     ("exact, every 64 consecutive reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
     ("exact, all reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
     ("exact, every 4 consecutive reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
+    ("low complexity (prefiltered)", (0.0, 0.0, 0.0, 1.0), 0.0),
+    ("off-target, all reads identical", (0.0, 1.0, 1.0, 1.0), 0.0),
 ]
 if os.environ.get("MIX_CASE"):
     CASES = [CASES[int(os.environ["MIX_CASE"])]]
@@ -34,7 +36,7 @@ for tag, mix, subst in CASES:
         reads = reads[::64].repeat_interleave(64, dim=0)[:N].contiguous()
     elif "every 4" in tag:
         reads = reads[::4].repeat_interleave(4, dim=0)[:N].contiguous()
-    elif "all reads identical" in tag:
+    elif "all reads identical" in tag or "identical" in tag.split(",")[-1]:
         reads = reads[:1].expand(N, -1).contiguous()
     torch.cuda.synchronize()
     best = None
