@@ -765,6 +765,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.node_ledge = ix->b_ledge.as<uint4>();
   d.unitig = ix->b_unitig.as<uint64_t>();
   d.all_local = fi.all_classes_local ? 1u : 0u;
+  d.uniform_windows = (fi.uniform_windows && env_u64("NIMBLE_UNIFORM_WINDOWS", 1) != 0) ? 1u : 0u;
   d.all_bitmaps = (fi.all_wide_have_bitmaps && env_u64("NIMBLE_WIDE_WINDOW", 1) != 0) ? 1u : 0u;
   d.cls_desc = ix->b_cls_desc.as<uint4>();
   d.cls_off = ix->b_cls_off.as<uint32_t>();

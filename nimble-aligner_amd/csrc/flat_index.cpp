@@ -284,7 +284,10 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
       uint32_t k = 0;
       auto put = [&](uint64_t b) {
         put_base(pos++, b);
-        if (k < NODE_INLINE_BASES) inl[k >> 5] |= b << (62 - 2 * (k & 31));
+        if (k >= NODE_INLINE_FIRST && k < NODE_INLINE_FIRST + NODE_INLINE_BASES) {
+          const uint32_t q = k - NODE_INLINE_FIRST;
+          inl[q >> 5] |= b << (62 - 2 * (q & 31));
+        }
         ++k;
       };
       uint64_t first = kmers[heads[nd]];
@@ -427,6 +430,51 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   for (size_t nd = 0; nd < n_nodes; ++nd) {
     const uint32_t c = out.node_rec[nd * 16 + 1];
     for (int k = 0; k < 4; ++k) out.node_rec[nd * 16 + 3 + k] = out.cls_desc[(size_t)c * 4 + k];
+  }
+  // Component windows.  The rows of a library row's k-mers hang together through the graph's edges, so a connected
+  // component of unitigs is a set of whole rows and the classes of two components share no row.  When the classes of
+  // every component span fewer than 64 rows, each node record gets its class mask relative to the component's first row.
+  if (out.all_classes_local && n_nodes) {
+    std::vector<uint32_t> parent(n_nodes);
+    for (size_t i = 0; i < n_nodes; ++i) parent[i] = (uint32_t)i;
+    auto root = [&](uint32_t x) {
+      while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+      }
+      return x;
+    };
+    for (size_t nd = 0; nd < n_nodes; ++nd) {
+      const uint32_t e = out.node_rec[nd * 16] >> 24;
+      for (uint32_t b = 0; b < 4; ++b)
+        if ((e >> 4) & (1u << b)) {
+          const uint32_t ra = root((uint32_t)nd), rb = root(out.node_rec[nd * 16 + 8 + b]);
+          if (ra != rb) parent[ra < rb ? rb : ra] = ra < rb ? ra : rb;
+        }
+    }
+    std::vector<uint32_t> lo(n_nodes, 0xFFFFFFFFu), hi(n_nodes, 0);
+    for (size_t nd = 0; nd < n_nodes; ++nd) {
+      const uint32_t r = root((uint32_t)nd);
+      const uint32_t base = out.node_rec[nd * 16 + 4];
+      const uint64_t m = (uint64_t)out.node_rec[nd * 16 + 5] | ((uint64_t)out.node_rec[nd * 16 + 6] << 32);
+      const uint32_t last = base + (m ? 63u - (uint32_t)__builtin_clzll(m) : 0u);
+      lo[r] = std::min(lo[r], base);
+      hi[r] = std::max(hi[r], last);
+    }
+    bool fits = true;
+    for (size_t nd = 0; nd < n_nodes && fits; ++nd)
+      if (parent[nd] == nd && hi[nd] - lo[nd] >= CLS_WINDOW) fits = false;
+    if (fits) {
+      for (size_t nd = 0; nd < n_nodes; ++nd) {
+        const uint32_t r = root((uint32_t)nd);
+        const uint32_t base = out.node_rec[nd * 16 + 4];
+        const uint64_t m = ((uint64_t)out.node_rec[nd * 16 + 5] | ((uint64_t)out.node_rec[nd * 16 + 6] << 32)) << (base - lo[r]);
+        out.node_rec[nd * 16 + 4] = lo[r];
+        out.node_rec[nd * 16 + 5] = (uint32_t)m;
+        out.node_rec[nd * 16 + 6] = (uint32_t)(m >> 32);
+      }
+      out.uniform_windows = true;
+    }
   }
   timer.lap("class descriptors");
 }

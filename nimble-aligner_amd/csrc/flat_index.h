@@ -16,7 +16,9 @@ namespace nimble {
 constexpr uint32_t KMER = 30;
 constexpr uint64_t KMER_MASK = (1ULL << (2 * KMER)) - 1;
 constexpr uint64_t HT_EMPTY = ~0ULL;
-constexpr uint32_t NODE_INLINE_BASES = 64;
+constexpr uint32_t NODE_INLINE_BASES = 64;   // bases a node record holds inline ...
+constexpr uint32_t NODE_INLINE_FIRST = KMER;  // ... starting at this base: the walk never compares a unitig's first k-mer
+                                              // (it is the seed, or the overlap with the unitig it came from)
 constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
 constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;
 constexpr uint32_t CLS_BITMAP_MAX_ROWS = 1u << 16;  // widest span a static class gets a row bitmap for (8 KiB)  // set in the descriptor's len word when the mask form is valid
@@ -161,9 +163,9 @@ struct FlatIndex {
   //   u32[5..6]   = class mask (lo, hi)
   //   u32[7]      = 0
   //   u32[8..11]  = right-edge target node per base
-  //   u32[12..15] = bases 0..63 (2 x u64, low word first), base i at word i>>5, bits 62-2*(i&31)
-  // plus a second record line used only by unitigs longer than 64 bases is avoided: bases 64.. come from
-  // the packed unitig buffer.
+  //   u32[12..15] = bases 30..93 (2 x u64, low word first), base 30 + i at word i>>5, bits 62-2*(i&31): what the forward
+  //                 walk compares in a unitig starts behind its first k-mer (NODE_INLINE_FIRST)
+  // bases from 94 on (and the first 30, for the left extension) come from the packed unitig buffer.
   std::vector<uint32_t> node_rec;    // 16 x u32 per node
   std::vector<uint32_t> node_ledge;  // 4 x u32 per node (left extension only)
   std::vector<uint64_t> unitig;      // 2-bit packed, base i at word i>>5, bits 62-2*(i&31)
@@ -176,6 +178,10 @@ struct FlatIndex {
   std::vector<uint32_t> cls_desc;    // 4 x u32 per class
   std::vector<uint64_t> cls_bits;    // row bitmaps of the classes wider than the mask form (cls_desc words 1..3)
   bool all_classes_local = true;     // every static class has the mask form
+  // ... and the classes of every connected component of the graph fit ONE 64-row window: the class descriptor inside a node
+  // record is then written relative to its component's first row (same base word for every unitig a walk can hop to), and
+  // the walk intersects without shifting (kernels.hip push_col)
+  bool uniform_windows = false;
   bool all_wide_have_bitmaps = true; // every static class outside the mask form has a row bitmap in cls_bits
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };

@@ -35,6 +35,7 @@ struct DevIndex {
   uint32_t *cls_ids;
   const uint64_t *cls_bits; // row bitmaps of the static classes wider than the mask form (see cls_desc)
   uint32_t all_local;       // every static class is in mask form: no colour list is kept during the walk
+  uint32_t uniform_windows; // ... and the masks in the node records are relative to their component's first row (flat_index.h)
   uint32_t all_bitmaps;     // every static class outside the mask form has a row bitmap (the walk may intersect in a
                             // 256-row register window instead of keeping the visited colours)
   uint32_t n_static;

@@ -412,6 +412,7 @@ struct Lane {
   // class of a gene lies inside), and neither a colour list nor a pass over it is needed
   bool window_ok;
   bool use_window;  // the index allows it (every wide class has a row bitmap)
+  bool uniform;     // the record masks are relative to their component's first row: equal bases, or nothing in common
   uint32_t wbase;
   uint64_t wacc[4];
   const uint64_t *cls_bits;
@@ -489,6 +490,11 @@ __device__ __forceinline__ uint64_t lds_bits(const uint64_t *rd, uint32_t pos, u
   const uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
   return funnel(rd[w * ALIGN_BLOCK], rd[(w + 1) * ALIGN_BLOCK], s) >> (64u - 2u * nb);
 }
+// the 32 bases from `pos` on, left-aligned
+__device__ __forceinline__ uint64_t lds_window(const uint64_t *rd, uint32_t pos) {
+  const uint32_t w = pos >> 5, s = (pos & 31u) * 2u;
+  return funnel(rd[w * ALIGN_BLOCK], rd[(w + 1) * ALIGN_BLOCK], s);
+}
 __device__ __forceinline__ uint32_t lds_base(const uint64_t *rd, uint32_t pos) {
   return (uint32_t)(rd[(pos >> 5) * ALIGN_BLOCK] >> (62u - 2u * (pos & 31u))) & 3u;
 }
@@ -497,14 +503,16 @@ __device__ __forceinline__ uint64_t g_bits(const uint64_t *__restrict__ u, uint6
   uint32_t s = (uint32_t)(pos & 31u) * 2u;
   return funnel(u[w], u[w + 1], s) >> (64u - 2u * nb);  // (the unitig buffer ends in spare words)
 }
-// nb bases of a unitig at node-relative position pos: from the record while inside its 64 inline bases
+// nb bases of a unitig at node-relative position pos: from the record while inside its 64 inline bases, which are the
+// bases [30, 94) -- the forward walk never looks at a unitig's first k-mer
 __device__ __forceinline__ uint64_t node_bits(const NodeRec &r, const uint64_t *__restrict__ unitig, uint32_t pos,
                                               uint32_t nb) {
-  if (pos + nb <= NODE_INLINE_BASES) {
+  const uint32_t q = pos - NODE_INLINE_FIRST;  // (wraps for pos < 30: the test below fails)
+  if (q + nb <= NODE_INLINE_BASES && pos >= NODE_INLINE_FIRST) {
     const uint64_t w0 = u64of(r.sq.x, r.sq.y), w1 = u64of(r.sq.z, r.sq.w);
-    const uint32_t s = (pos & 31u) * 2u;
-    const uint64_t hi = pos < 32u ? w0 : w1;
-    const uint64_t lo = pos < 32u ? w1 : 0ULL;
+    const uint32_t s = (q & 31u) * 2u;
+    const uint64_t hi = q < 32u ? w0 : w1;
+    const uint64_t lo = q < 32u ? w1 : 0ULL;
     return funnel(hi, lo, s) >> (64u - 2u * nb);
   }
   return g_bits(unitig, (uint64_t)r.q0.z + pos, nb);
@@ -686,7 +694,9 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 
   }
   const bool first_node = ln.walk_nodes == 0;
   ln.walk_nodes++;
-  ln.acc &= mask_in_window(desc, ln.fbase);  // idempotent: repeated colours cost nothing
+  // idempotent: repeated colours cost nothing.  Component-relative masks need no shift: a unitig of another component (a
+  // re-seed that landed in another gene family) shares no row with what was visited
+  ln.acc &= ln.uniform ? (desc.y == ln.fbase ? desc_mask(desc) : 0ULL) : mask_in_window(desc, ln.fbase);
   if (ln.keep_list) {
     ln.all_mask = ln.all_mask && desc_is_mask(desc);
     if (first_node) {
@@ -874,9 +884,14 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         n_left = tneed < informative ? tneed : informative;
       }
       bool prem = false;
+      uint32_t junction = 4u;  // 0..3: the read base at kmer_pos, known from the compare of this iteration; 4: not known
       if (n_left) {
         const uint32_t c = n_left < 32u ? n_left : 32u;
-        const uint64_t x = lds_bits(ln.rd, base0 + kmer_pos, c) ^ node_bits(nr, ix.unitig, upos, c);
+        // (the 32 read bases from kmer_pos on; the compare takes the first c, and the base behind them -- the one that
+        // picks the way out of the unitig when the stretch ends it -- comes out of the same window)
+        const uint64_t win = lds_window(ln.rd, base0 + kmer_pos);
+        junction = c < 32u ? (uint32_t)(win >> (62u - 2u * c)) & 3u : 4u;
+        const uint64_t x = (win >> (64u - 2u * c)) ^ node_bits(nr, ix.unitig, upos, c);
         uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
         const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t adv = c;
@@ -908,7 +923,9 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         tneed -= adv;
       }
       if (n_left == 0) {  // the unitig, or the tentative stretch, is done: a successor, a new seed, or the end
-        const uint32_t nbase = lds_base(ln.rd, base0 + kmer_pos);  // (the column ends in a zero word: safe at kmer_pos == L)
+        // the read base at kmer_pos (the column ends in a zero word: safe at kmer_pos == L); a compare that ran its whole
+        // stretch in this iteration has it already
+        const uint32_t nbase = (junction < 4u && !prem) ? junction : lds_base(ln.rd, base0 + kmer_pos);
         const bool edge = ((nr_exts(nr) >> 4) >> nbase) & 1u;
         if (tneed < NO_TENT / 2) {  // inside the tentative walk
           if (!prem && tneed == 0) {
@@ -1177,6 +1194,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
   ln.keep_list = WIDE;
   ln.window_ok = false;
   ln.use_window = WIDE && ix.all_bitmaps != 0;
+  ln.uniform = !WIDE && ix.uniform_windows != 0;
   ln.wbase = 0;
   ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = 0;
   ln.cls_bits = ix.cls_bits;
