@@ -898,12 +898,30 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         // the usual setting, and the tentative walk under any setting: the first mismatch ends the compare
         bool strict = allowed == 0;  // (uniform)
         if (!strict) strict = tneed < NO_TENT / 2;
-        if (strict) {  // selects, no branch
+        if (strict) {
           prem = cnt != 0;
           const uint32_t bit = 63u - (uint32_t)__clzll((long long)(m | 1ULL));
-          adv = prem ? c - 1u - (bit >> 1) : c;
-          mm += prem ? 1u : 0u;
-          n_left = prem ? 0u : n_left - c;
+          const uint32_t k = c - 1u - (bit >> 1);  // bases in front of the first differing one
+          adv = prem ? k : c;
+          bool on = false;
+          // A differing base p inside the stretch, the only one in it, and the walk not tentative yet: go on tentatively
+          // with the rest of this very stretch (it agrees) instead of ending the iteration at p -- the lane would otherwise
+          // spend an iteration on the split, and the wave runs as many iterations as its slowest lane.
+          if (NIMBLE_TENT && prem && cnt == 1u && tneed >= NO_TENT / 2 && ix.mleft && kmer_pos + k + 3u <= last_kmer_pos)
+            on = !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(ln.rd, base0 + kmer_pos + k + 1u, KMER - 1u));
+          if (on) {
+            const uint32_t r = c - 1u - k;  // bases of the stretch behind p
+            mm += 1;
+            prem = false;
+            adv = c;
+            cov -= 1;                       // (p itself is not counted; the r bases behind it are, tentatively)
+            tneed = 32u - r + c;            // (c comes off again below)
+            const uint32_t rest = n_left - c;
+            n_left = rest < 32u - r ? rest : 32u - r;
+          } else {
+            mm += prem ? 1u : 0u;
+            n_left = prem ? 0u : n_left - c;
+          }
         } else if (seen + cnt <= allowed) {
           seen += cnt;
           mm += cnt;
@@ -931,6 +949,8 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
           if (!prem && tneed == 0) {
             // all 32 bases behind p agree: the seed is the k-mer that ends with the last of them, in this unitig.  Enter it
             // the way a seed is entered (the record comes from L1 this time): kmer_pos = p + 3, nothing counted so far.
+            // (Pushing the unitig right here instead costs a second copy of push_col in the loop: measured 25 % slower
+            // on every kind of read -- the loop's register allocation does not survive it.)
             koff = upos - KMER;
             kmer_pos -= KMER;
             cov -= 32u;
@@ -958,13 +978,6 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
           st = ST_ENTER;
         } else if (kmer_pos >= L || kmer_pos > last_kmer_pos) {
           st = ST_DONE;
-        } else if (NIMBLE_TENT && prem && ix.mleft && kmer_pos + 3u <= last_kmer_pos &&
-                   !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(ln.rd, base0 + kmer_pos + 1u, KMER - 1u))) {
-          tneed = 32;
-          kmer_pos += 1;
-          upos += 1;
-          const uint32_t rest = nr_len(nr) - upos;
-          n_left = rest < 32u ? rest : 32u;
         } else {
           st = ST_SEED;  // dead end or mismatch budget exceeded: search the next seed from kmer_pos
         }
