@@ -95,6 +95,11 @@ int nimble_index_stats(const nimble_index *, uint64_t stats[8]);
  * colour classes; higher ids are intersections interned on the device.  Returns the class length in
  * *len; copies at most cap ids. */
 int nimble_class_get(const nimble_index *, uint32_t class_id, uint32_t *ids, uint32_t cap, uint32_t *len);
+/* The same for many classes at once (a host that meets thousands of new classes in one histogram -- allele families of a
+ * hundred rows -- must not pay a device round trip per class): lengths and pool offsets of the classes [first, first +
+ * count), then any slice of the id pool.  Classes that a call still in flight is interning may read as length 0. */
+int nimble_class_table_read(const nimble_index *, uint32_t first, uint32_t count, uint32_t *len, uint32_t *pool_off);
+int nimble_class_pool_read(const nimble_index *, uint32_t pool_off, uint32_t count, uint32_t *ids);
 
 /* Host-only diagnostic: builds the flat index exactly as nimble_index_build does but uploads nothing.
  * stats[0..4] as nimble_index_stats.  Lets CPU-only tests check the index builder. */

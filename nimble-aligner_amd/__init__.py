@@ -95,7 +95,7 @@ HIP_SYMBOLS = [
     "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl",
     "nimble_counts_allreduce", "nimble_counts_allreduce_host", "nimble_records_alltoall", "nimble_sharded_begin",
     "nimble_sharded_append", "nimble_sharded_end", "nimble_sharded_grow", "nimble_sharded_abort",
-    "nimble_steps_begin", "nimble_steps_submit", "nimble_steps_flush", "nimble_steps_end",
+    "nimble_class_table_read", "nimble_class_pool_read", "nimble_steps_begin", "nimble_steps_submit", "nimble_steps_flush", "nimble_steps_end",
 ]
 
 

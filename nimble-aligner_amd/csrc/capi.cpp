@@ -850,6 +850,27 @@ int nimble_class_get(const nimble_index *ix, uint32_t id, uint32_t *ids, uint32_
   return NIMBLE_OK;
 }
 
+int nimble_class_table_read(const nimble_index *ix, uint32_t first, uint32_t count, uint32_t *len, uint32_t *pool_off) {
+  if (!ix || (count && (!len || !pool_off))) return fail(NIMBLE_E_INVALID, "nimble_class_table_read: NULL argument");
+  if ((uint64_t)first + count > ix->dev.cls_cap) return fail(NIMBLE_E_INVALID, "nimble_class_table_read: beyond the class table");
+  if (count == 0) return NIMBLE_OK;
+  HIPCHK(hipSetDevice(ix->device));
+  std::vector<uint32_t> desc((size_t)count * 4);
+  HIPCHK(hipMemcpy(desc.data(), ix->dev.cls_desc + first, (size_t)count * 16, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pool_off, ix->dev.cls_off + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < count; ++k) len[k] = desc[(size_t)k * 4] & ~CLS_MASK_FLAG;
+  return NIMBLE_OK;
+}
+
+int nimble_class_pool_read(const nimble_index *ix, uint32_t pool_off, uint32_t count, uint32_t *ids) {
+  if (!ix || (count && !ids)) return fail(NIMBLE_E_INVALID, "nimble_class_pool_read: NULL argument");
+  if ((uint64_t)pool_off + count > ix->dev.ids_cap) return fail(NIMBLE_E_INVALID, "nimble_class_pool_read: beyond the id pool");
+  if (count == 0) return NIMBLE_OK;
+  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(hipMemcpy(ids, ix->dev.cls_ids + pool_off, (size_t)count * 4, hipMemcpyDeviceToHost));
+  return NIMBLE_OK;
+}
+
 int nimble_ctx_create(nimble_index *ix, void *stream, nimble_ctx **out) {
   if (!ix || !out) return fail(NIMBLE_E_INVALID, "nimble_ctx_create: NULL argument");
   *out = nullptr;

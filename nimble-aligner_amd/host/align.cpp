@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
+#include <thread>
 #include <unordered_set>
 
 #include "../../include/nimble_hip.h"
@@ -408,6 +410,33 @@ const std::vector<uint32_t> &PseudoAligner::eq_class(uint32_t id) {
   return class_cache_.emplace(id, std::move(v)).first->second;
 }
 
+void PseudoAligner::prefetch_classes(std::vector<uint32_t> ids) {
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  ids.erase(std::remove_if(ids.begin(), ids.end(), [&](uint32_t c) { return class_cache_.count(c) != 0; }), ids.end());
+  if (ids.size() < 16) return;  // (a handful: eq_class fetches them one by one)
+  // the table rows of [lo, hi] in two copies, then the slice of the id pool they point into in one
+  const uint32_t lo = ids.front(), hi = ids.back();
+  std::vector<uint32_t> len(hi - lo + 1), off(hi - lo + 1);
+  check_rc(nimble_class_table_read(index_, lo, hi - lo + 1, len.data(), off.data()), "nimble_class_table_read");
+  uint64_t plo = ~0ULL, phi = 0;
+  for (uint32_t c : ids) {
+    const uint32_t l = len[c - lo], o = off[c - lo];
+    if (l == 0) continue;
+    plo = std::min<uint64_t>(plo, o);
+    phi = std::max<uint64_t>(phi, (uint64_t)o + l);
+  }
+  if (plo >= phi) return;
+  if (phi - plo > (1ULL << 28)) return;  // (classes scattered over more than 1 GiB of the pool: leave it to eq_class)
+  std::vector<uint32_t> pool(phi - plo);
+  check_rc(nimble_class_pool_read(index_, (uint32_t)plo, (uint32_t)(phi - plo), pool.data()), "nimble_class_pool_read");
+  for (uint32_t c : ids) {
+    const uint32_t l = len[c - lo], o = off[c - lo];
+    if (l == 0) continue;
+    class_cache_.emplace(c, std::vector<uint32_t>(pool.begin() + (long)(o - plo), pool.begin() + (long)(o - plo + l)));
+  }
+}
+
 const std::vector<std::string> &RowRefs::features(size_t i) const { return memo->callsets.at((size_t)ids.at(i)); }
 
 const std::string &RowRefs::joined(size_t i) const {
@@ -598,6 +627,69 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
   // the `results` HashMap of align.rs:434, as dense counts over the memoised callsets
   static const std::vector<uint32_t> empty;
   memo.counts.assign(memo.callsets.size(), 0);
+  // Class pairs this memo has not met: their classes come over in bulk and they are coerced by all host threads (the
+  // coercion is a pure function of the pair); a library of allele families leaves 10^5 new pairs in its first histograms
+  // -- one by one, with a device round trip per class, that was 10 s for 4 M reads.
+  {
+    std::vector<uint64_t> fresh;
+    for (uint64_t e = 0; e < ne; ++e) {
+      const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
+      if (!memo.pairs.find(key)) fresh.push_back(e);
+    }
+    if (fresh.size() >= 64) {
+      std::vector<uint32_t> need;
+      for (uint64_t e : fresh) {
+        if (c1[e] != NIMBLE_CLASS_NONE) need.push_back(c1[e]);
+        if (c2[e] != NIMBLE_CLASS_NONE) need.push_back(c2[e]);
+      }
+      index.prefetch_classes(std::move(need));
+      static const std::vector<uint32_t> none;
+      std::vector<const std::vector<uint32_t> *> k1(fresh.size()), k2(fresh.size());
+      for (size_t i = 0; i < fresh.size(); ++i) {  // (eq_class fills the cache: not from the worker threads)
+        const uint64_t e = fresh[i];
+        k1[i] = c1[e] != NIMBLE_CLASS_NONE ? &index.eq_class(c1[e]) : &none;
+        k2[i] = c2[e] != NIMBLE_CLASS_NONE ? &index.eq_class(c2[e]) : &none;
+      }
+      std::vector<std::vector<std::string>> sets(fresh.size());
+      std::vector<FilterReason> tri(fresh.size());
+      const unsigned threads = std::max(1u, std::min(parse::usable_cpus(), 32u));
+      std::atomic<size_t> next{0};
+      std::vector<std::thread> pool;
+      std::vector<std::exception_ptr> err(threads);
+      for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+          try {
+            for (size_t i = next.fetch_add(256); i < fresh.size(); i = next.fetch_add(256))
+              for (size_t j = i; j < std::min(fresh.size(), i + 256); ++j) {
+                const uint64_t e = fresh[j];
+                sets[j] = memo.coercer->coerce(c1[e] != NIMBLE_CLASS_NONE, *k1[j], c2[e] != NIMBLE_CLASS_NONE, *k2[j], tri[j]);
+              }
+          } catch (...) {
+            err[t] = std::current_exception();
+          }
+        });
+      for (auto &th : pool) th.join();
+      for (auto &x : err)
+        if (x) std::rethrow_exception(x);
+      for (size_t i = 0; i < fresh.size(); ++i) {  // into the memo in histogram order, as the serial loop would
+        const uint64_t e = fresh[i];
+        const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
+        if (memo.pairs.find(key)) continue;
+        int32_t id = -1;
+        if (!sets[i].empty()) {
+          auto ins = memo.callset_ids.emplace(sets[i], (int32_t)memo.callsets.size());
+          if (ins.second) {
+            memo.callsets.push_back(std::move(sets[i]));
+            memo.counts.push_back(0);
+            memo.sorted.clear();
+          }
+          id = ins.first->second;
+        }
+        if (id < 0) memo.pair_triage[key] = tri[i];
+        memo.pairs.insert(key, id);
+      }
+    }
+  }
   for (uint64_t e = 0; e < ne; ++e) {
     const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
     const int32_t *hit = memo.pairs.find(key);

@@ -132,6 +132,8 @@ class PseudoAligner {
   // is a third call slot (the align-where-the-reads-are pipeline keeps three calls open)
   nimble_ctx *ctx(int slot = 0);
   const std::vector<uint32_t> &eq_class(uint32_t class_id);  // cached nimble_class_get
+  // fetch the classes of `ids` that are not cached yet with a few bulk copies (nimble_class_table_read / _pool_read)
+  void prefetch_classes(std::vector<uint32_t> ids);
 
   // Coercion memo: class ids are stable for the life of the index, and the coercion of a class pair depends
   // only on (Reference names / groups, the coercion part of the config).  The memo is keyed by an exact
