@@ -352,6 +352,10 @@ int nimble_sharded_begin(nimble_comm *, int rank, nimble_ctx *, const nimble_ali
                          uint32_t max_len);
 int nimble_sharded_append(nimble_comm *, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
                           const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem);
+/* the same round with reads the host has packed to 2 bits (host memory; layout of nimble_stream_append_packed): a quarter
+ * of the bytes cross the link */
+int nimble_sharded_append_packed(nimble_comm *, int rank, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
+                                 const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t n);
 int nimble_sharded_end(nimble_comm *, int rank, uint64_t *n_owned);
 /* A later batch holds a read longer than the call was opened for: every rank widens the records it has kept to the new
  * max_len (a local device copy, nothing is exchanged and nothing re-read; the key hash covers the bases, not the record

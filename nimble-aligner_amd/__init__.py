@@ -94,7 +94,7 @@ HIP_SYMBOLS = [
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
     "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl",
     "nimble_counts_allreduce", "nimble_counts_allreduce_host", "nimble_records_alltoall", "nimble_sharded_begin",
-    "nimble_sharded_append", "nimble_sharded_end", "nimble_sharded_grow", "nimble_sharded_abort",
+    "nimble_sharded_append", "nimble_sharded_append_packed", "nimble_sharded_end", "nimble_sharded_grow", "nimble_sharded_abort",
     "nimble_class_table_read", "nimble_class_pool_read", "nimble_steps_begin", "nimble_steps_submit", "nimble_steps_flush", "nimble_steps_end",
 ]
 
@@ -165,6 +165,7 @@ def hip_lib():
         L.nimble_records_alltoall.argtypes = [vp, i32, vp, vp, u32, vp, u64, C.POINTER(u64), vp]
         L.nimble_sharded_begin.argtypes = [vp, i32, vp, C.POINTER(AlignParams), i32, u32]
         L.nimble_sharded_append.argtypes = [vp, i32, vp, vp, vp, vp, u64, u32, i32]
+        L.nimble_sharded_append_packed.argtypes = [vp, i32, vp, vp, u32, vp, vp, u32, u64]
         L.nimble_sharded_end.argtypes = [vp, i32, C.POINTER(u64)]
         L.nimble_sharded_grow.argtypes = [vp, i32, u32]
         L.nimble_steps_begin.argtypes = [vp, i32, vp, vp, vp, C.POINTER(AlignParams), i32, u32]

@@ -2255,9 +2255,20 @@ int nimble_sharded_begin(nimble_comm *c, int rank, nimble_ctx *ctx, const nimble
   return NIMBLE_OK;
 }
 
-int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
-                          const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem) {
-  DRAIN_STALE_HIP_ERROR();
+// what an append is given: ASCII reads (host or device memory) or reads the host has packed to 2 bits (host memory)
+struct ShardedIn {
+  const uint8_t *r1 = nullptr, *r2 = nullptr;
+  const uint64_t *r1_off = nullptr, *r2_off = nullptr;
+  uint32_t fixed_len = 0;
+  int mem = NIMBLE_MEM_HOST;
+  const uint64_t *w1 = nullptr, *w2 = nullptr;  // packed form: words, lengths, words per read
+  const uint32_t *l1 = nullptr, *l2 = nullptr;
+  uint32_t s1 = 0, s2 = 0;
+  bool packed = false;
+  bool has_mates() const { return packed ? w2 != nullptr : r2 != nullptr; }
+};
+
+static int sharded_append_impl(nimble_comm *c, int rank, const ShardedIn &in, uint64_t n) {
   if (!c || rank < 0 || rank >= c->n) return fail(NIMBLE_E_INVALID, "nimble_sharded_append: bad argument");
   nimble_comm::Shard &sh = c->shard[rank];
   nimble_ctx *ctx = sh.ctx;
@@ -2265,19 +2276,56 @@ int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uin
   // (a failure of one rank must not leave the others waiting at a barrier: local errors are carried to the collectives)
   int rc = sh.open ? NIMBLE_OK : fail(NIMBLE_E_INVALID, "nimble_sharded_append: no sharded call is open on this rank");
   uint32_t max_len = sh.max_len;
-  if (rc == NIMBLE_OK && (r2 != nullptr) != (sh.paired != 0)) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: mates given for a single-end call or missing for a paired one");
-  if (rc == NIMBLE_OK && !r1_off && fixed_len > max_len) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: a read longer than max_len");
-  if (rc == NIMBLE_OK) rc = check_read_args(r1, r1_off, r2, r2_off, n, fixed_len, max_len, mem);
+  if (rc == NIMBLE_OK && in.has_mates() != (sh.paired != 0)) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: mates given for a single-end call or missing for a paired one");
+  if (rc == NIMBLE_OK && !in.packed) {
+    if (!in.r1_off && in.fixed_len > max_len) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: a read longer than max_len");
+    if (rc == NIMBLE_OK) rc = check_read_args(in.r1, in.r1_off, in.r2, in.r2_off, n, in.fixed_len, max_len, in.mem);
+  }
+  if (rc == NIMBLE_OK && in.packed && n) {
+    if (!in.w1 || !in.l1 || in.s1 == 0 || (in.w2 && (!in.l2 || in.s2 == 0)))
+      rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append_packed: NULL buffer or zero stride");
+    for (int mt = 0; rc == NIMBLE_OK && mt < (in.w2 ? 2 : 1); ++mt) {
+      const uint32_t *len = mt ? in.l2 : in.l1;
+      const uint64_t cap = std::min<uint64_t>(max_len, 32ULL * (mt ? in.s2 : in.s1));
+      for (uint64_t i = 0; i < n; ++i)
+        if (len[i] > cap) {
+          rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append_packed: a read longer than max_len or than its words");
+          break;
+        }
+    }
+  }
   std::vector<uint64_t> counts(W, 0);
   const uint32_t rw = sh.rec_words;
   if (rc == NIMBLE_OK && hipSetDevice(c->devices[rank]) != hipSuccess) rc = fail(NIMBLE_E_HIP, "hipSetDevice");
   if (rc == NIMBLE_OK && n) {
     if (ctx->called && !ctx->finished) rc = fail(NIMBLE_E_INVALID, "nimble_sharded_append: the context holds a call in flight");
-    if (rc == NIMBLE_OK) rc = stage_inputs(ctx, r1, r1_off, r2, r2_off, n, fixed_len, sh.max_len, mem);
-    if (rc == NIMBLE_OK) rc = setup_call(ctx, &sh.prm, n, r2 != nullptr, sh.max_len, nullptr);
-    if (rc == NIMBLE_OK) {
+    if (rc == NIMBLE_OK && !in.packed) rc = stage_inputs(ctx, in.r1, in.r1_off, in.r2, in.r2_off, n, in.fixed_len, sh.max_len, in.mem);
+    if (rc == NIMBLE_OK) rc = setup_call(ctx, &sh.prm, n, in.has_mates(), sh.max_len, nullptr);
+    if (rc == NIMBLE_OK && hipMemsetAsync((uint64_t *)ctx->b_state.p + 14, 0, 8, ctx->stream) != hipSuccess)
+      rc = fail(NIMBLE_E_HIP, "hipMemsetAsync");
+    if (rc == NIMBLE_OK && in.packed) {
+      // the packed batch goes over in two copies per mate on the rank's stream, k_pack_words reads it there
+      const uint64_t *d_words[2] = {nullptr, nullptr};
+      const uint32_t *d_len[2] = {nullptr, nullptr};
+      for (int mt = 0; rc == NIMBLE_OK && mt < (in.w2 ? 2 : 1); ++mt) {
+        const uint64_t wbytes = n * (uint64_t)(mt ? in.s2 : in.s1) * 8;
+        rc = ctx->b_stage[0][mt].ensure(std::max<uint64_t>(wbytes, 16), &ctx->bytes);
+        if (rc == NIMBLE_OK) rc = ctx->b_stage_off[0][mt].ensure(std::max<uint64_t>(n * 4, 16), &ctx->bytes);
+        if (rc == NIMBLE_OK &&
+            (hipMemcpyAsync(ctx->b_stage[0][mt].p, mt ? in.w2 : in.w1, wbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(ctx->b_stage_off[0][mt].p, mt ? in.l2 : in.l1, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+          rc = fail(NIMBLE_E_HIP, "nimble_sharded_append_packed: copy to the device failed");
+        d_words[mt] = ctx->b_stage[0][mt].as<uint64_t>();
+        d_len[mt] = ctx->b_stage_off[0][mt].as<uint32_t>();
+      }
+      if (rc == NIMBLE_OK)
+        launch_pack_words(ctx->stream, d_words[0], d_len[0], in.s1, d_words[1], d_len[1], in.s2, sh.max_len,
+                          ctx->prm.min_read_length, ctx->b_plog.as<double>(), ctx->cb);
+    } else if (rc == NIMBLE_OK) {
       launch_pack(ctx->stream, ctx->in_r[0], ctx->in_off[0], ctx->in_r[1], ctx->in_off[1], ctx->in_fixed_len, ctx->in_max_len,
                   ctx->prm.min_read_length, ctx->b_plog.as<double>(), ctx->plog_max_len, ctx->cb);
+    }
+    if (rc == NIMBLE_OK) {
       const uint64_t cells = (uint64_t)route_grid() * W;
       rc = ctx->b_route.ensure(cells * 4 + cells * 8 + 256 * 8, &ctx->bytes);
       if (rc == NIMBLE_OK) rc = sh.send.ensure(std::max<uint64_t>(n * rw * 8, 16), nullptr);
@@ -2336,6 +2384,33 @@ int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uin
   if (c->rccl) HIPCHK(hipStreamSynchronize(ctx->stream));
   sh.n_acc += got;
   return NIMBLE_OK;
+}
+
+int nimble_sharded_append(nimble_comm *c, int rank, const uint8_t *r1, const uint64_t *r1_off, const uint8_t *r2,
+                          const uint64_t *r2_off, uint64_t n, uint32_t fixed_len, int mem) {
+  DRAIN_STALE_HIP_ERROR();
+  ShardedIn in;
+  in.r1 = r1;
+  in.r1_off = r1_off;
+  in.r2 = r2;
+  in.r2_off = r2_off;
+  in.fixed_len = fixed_len;
+  in.mem = mem;
+  return sharded_append_impl(c, rank, in, n);
+}
+
+int nimble_sharded_append_packed(nimble_comm *c, int rank, const uint64_t *r1_words, const uint32_t *r1_len, uint32_t r1_stride,
+                                 const uint64_t *r2_words, const uint32_t *r2_len, uint32_t r2_stride, uint64_t n) {
+  DRAIN_STALE_HIP_ERROR();
+  ShardedIn in;
+  in.packed = true;
+  in.w1 = r1_words;
+  in.l1 = r1_len;
+  in.s1 = r1_stride;
+  in.w2 = r2_words;
+  in.l2 = r2_len;
+  in.s2 = r2_stride;
+  return sharded_append_impl(c, rank, in, n);
 }
 
 int nimble_sharded_grow(nimble_comm *c, int rank, uint32_t max_len) {

@@ -1255,9 +1255,9 @@ void process_sharded(const std::vector<std::string> &input_files,
     align::device_params(aligner_configs.at(li), &prm);
     uint32_t max_len = 0;
     {
-      Cursor c1(input_files.at(0), false, batch, false);  // (the sharded append takes ASCII)
+      Cursor c1(input_files.at(0), false, batch, true);  // (batches travel packed: nimble_sharded_append_packed)
       std::unique_ptr<Cursor> c2;
-      if (paired) c2.reset(new Cursor(input_files[1], true, batch, false));
+      if (paired) c2.reset(new Cursor(input_files[1], true, batch, true));
       bool begun = false;
       // a failure between begin and end leaves no rank with an open call (the contexts are used again by the next library)
       struct OpenGuard {
@@ -1293,12 +1293,25 @@ void process_sharded(const std::vector<std::string> &input_files,
           const uint64_t *o2 = paired ? c2->b->data.offsets.data() + c2->used : nullptr;
           const uint8_t *b1 = c1.b->data.bases.data();
           const uint8_t *b2 = paired ? c2->b->data.bases.data() : nullptr;
-          // one round: rank r packs reads [n r / W, n (r + 1) / W) of the slice, the packed reads go to their owners
+          // one round: rank r takes reads [n r / W, n (r + 1) / W) of the slice -- as the 2-bit words the parser threads
+          // made of them when the batch carries them (a quarter of the bytes over the link), else as text -- and the
+          // packed reads go to their owners
+          const bool words = c1.b->stride != 0 && (!paired || c2->b->stride != 0);
           on_every_rank(W, [&](int r) {
             const uint64_t lo = n * (uint64_t)r / (uint64_t)W, hi = n * (uint64_t)(r + 1) / (uint64_t)W;
-            check_dev(nimble_sharded_append(comm, r, b1, o1 + lo, b2, paired ? o2 + lo : nullptr, hi - lo, 0,
-                                            NIMBLE_MEM_HOST),
-                      "nimble_sharded_append");
+            if (words) {
+              const uint64_t a1 = c1.used + lo, a2 = paired ? c2->used + lo : 0;
+              check_dev(nimble_sharded_append_packed(comm, r, c1.b->words.data() + a1 * (uint64_t)c1.b->stride,
+                                                     c1.b->lens.data() + a1, c1.b->stride,
+                                                     paired ? c2->b->words.data() + a2 * (uint64_t)c2->b->stride : nullptr,
+                                                     paired ? c2->b->lens.data() + a2 : nullptr, paired ? c2->b->stride : 0u,
+                                                     hi - lo),
+                        "nimble_sharded_append_packed");
+            } else {
+              check_dev(nimble_sharded_append(comm, r, b1, o1 + lo, b2, paired ? o2 + lo : nullptr, hi - lo, 0,
+                                              NIMBLE_MEM_HOST),
+                        "nimble_sharded_append");
+            }
           });
           c1.used += n;
           if (paired) c2->used += n;
