@@ -11,7 +11,8 @@ rank holds its own reads (weak scaling) and a step is partition -> all-to-all ex
 
 Other workloads (--workload): `configs4` = BASELINE.json configs[4], 80 M reads in total split over the ranks against a
 5 k-feature library; `configs3` = configs[3], paired-end 2x150 with the mismatch.json settings; `families100` = a library of
-gene families of 100 alleles at 1 % divergence (the shape of the reference's own MHC fixtures), same reads recipe.
+gene families of 100 alleles at 1 % divergence (the shape of the reference's own MHC fixtures), same reads recipe;
+`families500` = families of 500 alleles (classes beyond the 256-row register window: the LDS row window).
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel (k_align,
 HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box's host cores), plus `step_ms` (min / median
@@ -51,6 +52,10 @@ WORKLOADS = {
     "families100": dict(features=1000, family=100, paired=False, reads=4_000_000, total=False,
                         text="allele families of 100 (not a BASELINE.json config): %(n)d x 150bp single-end reads per GPU vs "
                              "%(T)d features = %(fam)d gene families of 100 alleles at 1 %% divergence (%(rows)d index rows), "
+                             "basic.json settings, unstranded"),
+    "families500": dict(features=2000, family=500, paired=False, reads=2_000_000, total=False,
+                        text="allele families of 500 (not a BASELINE.json config): %(n)d x 150bp single-end reads per GPU vs "
+                             "%(T)d features = %(fam)d gene families of 500 alleles at 1 %% divergence (%(rows)d index rows), "
                              "basic.json settings, unstranded"),
 }
 

@@ -767,6 +767,12 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.all_local = fi.all_classes_local ? 1u : 0u;
   d.uniform_windows = (fi.uniform_windows && env_u64("NIMBLE_UNIFORM_WINDOWS", 1) != 0) ? 1u : 0u;
   d.all_bitmaps = (fi.all_wide_have_bitmaps && env_u64("NIMBLE_WIDE_WINDOW", 1) != 0) ? 1u : 0u;
+  // bitmaps longer than the 256-row register window (allele families of several hundred rows): the window moves to LDS, as
+  // many words per lane as the longest bitmap has (at most NIMBLE_LDS_WINDOW_WORDS, default 32 = 2048 rows = 64 KiB per
+  // block; classes beyond that keep the colour list); NIMBLE_LDS_WINDOW=0 switches it off
+  d.window_words = 0;
+  if (d.all_bitmaps && fi.max_bitmap_words > 4 && env_u64("NIMBLE_LDS_WINDOW", 1) != 0)
+    d.window_words = (uint32_t)std::min<uint64_t>(fi.max_bitmap_words, env_u64("NIMBLE_LDS_WINDOW_WORDS", 32));
   d.cls_desc = ix->b_cls_desc.as<uint4>();
   d.cls_off = ix->b_cls_off.as<uint32_t>();
   d.cls_ids = ix->b_cls_ids.as<uint32_t>();

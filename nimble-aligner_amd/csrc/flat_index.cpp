@@ -422,6 +422,7 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
         out.cls_desc[c * 4 + 1] = first;
         out.cls_desc[c * 4 + 2] = span;
         out.cls_desc[c * 4 + 3] = (uint32_t)at + 1u;
+        out.max_bitmap_words = std::max(out.max_bitmap_words, (span + 63u) / 64u);
       } else {
         out.all_wide_have_bitmaps = false;
       }

@@ -183,6 +183,7 @@ struct FlatIndex {
   // the walk intersects without shifting (kernels.hip push_col)
   bool uniform_windows = false;
   bool all_wide_have_bitmaps = true; // every static class outside the mask form has a row bitmap in cls_bits
+  uint32_t max_bitmap_words = 0;     // ... and the longest of those bitmaps, in 64-row words (sizes the device's row window)
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;
 };
 

@@ -38,6 +38,8 @@ struct DevIndex {
   uint32_t uniform_windows; // ... and the masks in the node records are relative to their component's first row (flat_index.h)
   uint32_t all_bitmaps;     // every static class outside the mask form has a row bitmap (the walk may intersect in a
                             // 256-row register window instead of keeping the visited colours)
+  uint32_t window_words;    // ... or, when some bitmap is longer than 256 rows, in an LDS window of this many 64-row words per lane
+                            // (0 = the register window)
   uint32_t n_static;
   uint32_t cls_cap;       // capacity in classes
   uint32_t ids_cap;       // capacity of cls_ids

@@ -415,6 +415,10 @@ struct Lane {
   bool uniform;     // the record masks are relative to their component's first row: equal bases, or nothing in common
   uint32_t wbase;
   uint64_t wacc[4];
+  // an index whose class bitmaps are longer than that (allele families of several hundred rows) keeps the window in an LDS
+  // column of the lane instead: wcap words (stride ALIGN_BLOCK), wn of them in use for the read at hand
+  uint64_t *wl;
+  uint32_t wn, wcap;
   const uint64_t *cls_bits;
   uint32_t probes, nodes;
   uint64_t entries;
@@ -703,13 +707,45 @@ __device__ __forceinline__ void push_col(Lane &ln, uint32_t colour, const uint4 
       // the window starts at a multiple of 64 rows, like the class bitmaps: one window word = one bitmap word
       ln.wbase = desc.y & ~63u;
       const uint32_t end = desc_is_mask(desc) ? desc.y + 64u : desc.y + desc.z;  // one past the last row it can hold
-      ln.window_ok = ln.use_window && end - ln.wbase <= WIDE_ROWS;
-      ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = ~0ULL;
+      if (ln.wl) {
+        ln.wn = (end - ln.wbase + 63u) >> 6;
+        ln.window_ok = ln.use_window && ln.wn <= ln.wcap;
+        if (ln.window_ok)
+          for (uint32_t q = 0; q < ln.wn; ++q) ln.wl[q * ALIGN_BLOCK] = ~0ULL;
+      } else {
+        ln.window_ok = ln.use_window && end - ln.wbase <= WIDE_ROWS;
+        ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = ~0ULL;
+      }
     }
     if (ln.n_cols && colour == ln.last_col) return;
     if (ln.window_ok) {
       ln.last_col = colour;
       ln.n_cols = 1;
+      if (ln.wl) {  // (uniform) the window in LDS: same folding, word by word
+        if (desc_is_mask(desc)) {
+          for (uint32_t q = 0; q < ln.wn; ++q) ln.wl[q * ALIGN_BLOCK] &= mask_in_window(desc, ln.wbase + 64u * q);
+        } else {
+          const uint64_t *__restrict__ w = ln.cls_bits + (desc.w - 1u);
+          const uint32_t n_words = (desc.z + 63u) >> 6;
+          const int32_t k0 = ((int32_t)ln.wbase - (int32_t)desc.y) >> 6;
+          // WCH words at a time: their bitmap loads go out together (one latency per chunk, not one per word) and fold into
+          // the window with ds_and -- no read of the window, nothing for the next chunk's loads to wait for.  (Chunks of 4 / 8 /
+          // 12 words: the same time; pairs of words per 16-byte load: slower, profiles/r03_experiments.txt 13.)
+          constexpr uint32_t WCH = 8;
+          for (uint32_t q0 = 0; q0 < ln.wn; q0 += WCH) {
+            uint64_t g[WCH];
+#pragma unroll
+            for (uint32_t j = 0; j < WCH; ++j) {
+              const int32_t k = k0 + (int32_t)(q0 + j);
+              g[j] = (q0 + j < ln.wn && k >= 0 && (uint32_t)k < n_words) ? w[k] : 0ULL;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < WCH; ++j)
+              if (q0 + j < ln.wn) atomicAnd((unsigned long long *)&ln.wl[(q0 + j) * ALIGN_BLOCK], (unsigned long long)g[j]);
+          }
+        }
+        return;
+      }
       if (desc_is_mask(desc)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ln.wacc[q] &= mask_in_window(desc, ln.wbase + 64u * (uint32_t)q);
@@ -1108,10 +1144,9 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
       uint32_t count = 0, first_id = 0, last_id = 0;
       uint64_t gmask = 0;
       uint64_t h = class_hash_init();
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        for (uint64_t m = ln.wacc[q]; m; m &= m - 1) {
-          const uint32_t id = ln.wbase + 64u * (uint32_t)q + (uint32_t)__ffsll((long long)m) - 1u;
+      auto take = [&](uint32_t q, uint64_t word) {
+        for (uint64_t m = word; m; m &= m - 1) {
+          const uint32_t id = ln.wbase + 64u * q + (uint32_t)__ffsll((long long)m) - 1u;
           if (out) out[count] = id;
           h = class_hash_step(h, id);
           if (count == 0) first_id = id;
@@ -1119,6 +1154,13 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
           if (id - first_id < 64u) gmask |= 1ULL << (id - first_id);
           ++count;
         }
+      };
+      if (ln.wl) {
+        for (uint32_t q = 0; q < ln.wn; ++q) take(q, ln.wl[q * ALIGN_BLOCK]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) take((uint32_t)q, ln.wacc[q]);
+      }
       hash = class_hash_final(h, count);
       if (count && last_id - first_id < 64u) {  // the result fits the mask form: same rule as everywhere
         hash = class_hash_mask(count, first_id, gmask);
@@ -1150,11 +1192,23 @@ __device__ uint32_t finish_class(const DevIndex &ix, const Lane &ln, uint64_t &h
 
 // number of rows in the register window (cheap: the class itself is only spelled out when somebody needs it)
 __device__ __forceinline__ uint32_t window_count(const Lane &ln) {
+  if (ln.wl) {
+    uint32_t c = 0;
+    for (uint32_t q = 0; q < ln.wn; ++q) c += (uint32_t)__popcll(ln.wl[q * ALIGN_BLOCK]);
+    return c;
+  }
   return (uint32_t)(__popcll(ln.wacc[0]) + __popcll(ln.wacc[1]) + __popcll(ln.wacc[2]) + __popcll(ln.wacc[3]));
 }
 // is interned class `id` (ascending ids in cls_ids, `count` of them) exactly the content of the register window?
 __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const Lane &ln, uint32_t id, uint32_t count) {
   const uint32_t *__restrict__ ids = ix.cls_ids + ix.cls_off[id];
+  if (ln.wl) {
+    for (uint32_t t = 0; t < count; ++t) {
+      const uint32_t off = ids[t] - ln.wbase, q = off >> 6;  // (wraps far above the window for a row below it)
+      if (q >= ln.wn || !((ln.wl[q * ALIGN_BLOCK] >> (off & 63u)) & 1ULL)) return false;
+    }
+    return true;
+  }
   for (uint32_t t = 0; t < count; ++t) {
     const uint32_t off = ids[t] - ln.wbase;  // wraps far above WIDE_ROWS for a row below the window
     const uint32_t q = off >> 6;
@@ -1210,6 +1264,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
   ln.uniform = !WIDE && ix.uniform_windows != 0;
   ln.wbase = 0;
   ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = 0;
+  ln.wcap = WIDE ? ix.window_words : 0u;
+  ln.wn = 0;
+  ln.wl = ln.wcap ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) + LDS_COLS * ALIGN_BLOCK) + ALIGN_LDS_EXTRA) + tid
+                  : nullptr;
   ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
   const uint64_t n = cb.n;
@@ -2203,7 +2261,8 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   const uint32_t nm = cb.paired ? 2u : 1u;
   const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
   const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
-  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA;
+  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
+                     (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
   const void *fn = align_kernel(cb.paired != 0, want_counters != 0, wide);
   // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
   // empty round); tiles are handed out through a counter.  Residency and the opt-in to more dynamic LDS than the

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("configs2", ["--reads", "60000", "--features", "64", "--e2e-reads", "20000", "--packed-input", "1"]),
     ("configs3", ["--reads", "30000", "--features", "64", "--e2e-reads", "0"]),
     ("families100", ["--reads", "20000", "--e2e-reads", "0"]),
+    ("families500", ["--reads", "20000", "--e2e-reads", "0"]),
 ])
 def test_bench_workloads_run_and_check_parity(workload, extra):
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1",

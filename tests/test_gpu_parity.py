@@ -276,14 +276,22 @@ def test_wide_classes_general_intersection_path():
     assert st["dynamic_classes"] > 0  # intersections that are not k-mer colours were interned on the device
 
 
-@pytest.mark.parametrize("sizes,n_reads", [((150, 70, 150, 3), 8000), ((500, 100, 20), 3000)])
-def test_large_allele_families_bitmap_intersection(sizes, n_reads):
+@pytest.mark.parametrize("sizes,n_reads,env", [
+    ((150, 70, 150, 3), 8000, {}),
+    ((500, 100, 20), 3000, {}),                                   # bitmaps of 9 words: the LDS row window
+    ((500, 300, 100), 3000, {"NIMBLE_LDS_WINDOW_WORDS": "6"}),     # ... capped at 6 words: the family of 500 keeps the colour list
+    ((500, 100, 20), 3000, {"NIMBLE_LDS_WINDOW": "0"}),           # ... switched off: register window or colour list
+])
+def test_large_allele_families_bitmap_intersection(sizes, n_reads, env, monkeypatch):
     """Families of 20 to 500 alleles at 1 % divergence (what an immune-gene library looks like): the classes of the
     shared k-mers span hundreds of neighbouring rows, beyond the 64-row mask form.  A walk whose first class spans at
     most 256 rows folds the row bitmaps of the visited classes into a register window (families of 70 and 100 here, at
-    row offsets that are no multiples of 64); wider ones keep the visited colours and intersect the bitmaps word by word
-    afterwards (intersect_general: families of 150 and 500).  Table, per-read records and class contents against the
-    oracle."""
+    row offsets that are no multiples of 64); an index that holds longer bitmaps keeps the window in an LDS column of the
+    lane, as many 64-row words as its longest bitmap (families of 500: 9 words); classes beyond the window's cap, or every
+    wide class when the window is switched off, keep the visited colours and intersect the bitmaps word by word afterwards
+    (intersect_general).  Table, per-read records, work counters and class contents against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(23 + len(sizes))
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     names, seqs = [], []
