@@ -177,6 +177,10 @@ def main():
     ap.add_argument("--native", type=int, default=1,
                     help="multi-GPU under torch.distributed.run: after the torch form, rank 0 also runs the native form over "
                          "all N devices (0 = skip); the line's value is the faster of the forms that ran and passed parity")
+    ap.add_argument("--native-child", type=int, default=0,
+                    help="(internal) run ONLY the native form over that many devices and print its JSON object: how rank 0 of "
+                         "a torch.distributed.run launch starts it, as a child process with a time limit")
+    ap.add_argument("--native-timeout", type=float, default=600.0, help="time limit of that child, seconds")
     ap.add_argument("--native-virtual", type=int, default=0,
                     help="rehearsal of the native form on ONE GPU: that many ranks share device 0 (device copies instead of RCCL)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
@@ -244,9 +248,14 @@ def main():
     lib_obj = synth.library_json(names, seqs)
     if args.workload == "configs3":  # mismatch.json settings with num_mismatches 2 (tests/mismatch.rs:45, basic-cases.rs:119)
         lib_obj[0].update(score_percent=0.08, score_threshold=12, num_mismatches=2)
+    n_sets = max(1, args.read_sets)
+    if args.native_child:
+        devs = [0] * args.native_virtual if args.native_virtual else list(range(args.native_child))
+        print(json.dumps(native_leg(nim, synth, torch, lib_obj, seqs, devs, n, L, n_sets, max(args.warmup, 3), args.steps)),
+              flush=True)
+        return
     lib = nim.Library(text=json.dumps(lib_obj), strand_filter="unstranded").build_index(local_rank)
     ctx = lib.device_context()
-    n_sets = max(1, args.read_sets)
     if paired:
         sets = []
         for k in range(n_sets):
@@ -569,7 +578,23 @@ def main():
         if want_native:
             devs = [0] * args.native_virtual if args.native_virtual else list(range(args.gpus if native_only else world))
             try:
-                nat = native_leg(nim, synth, torch, lib_obj, seqs, devs, n, L, n_sets, max(args.warmup, 3), args.steps)
+                if world > 1:
+                    # a process of its own with a time limit: a fault or a hang inside the second form (its RCCL path has
+                    # its first N-device run in exactly this place) must not take the measured line of the first with it
+                    env = {k: v for k, v in os.environ.items()
+                           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                        "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                    cmd = [sys.executable, os.path.abspath(__file__), "--native-child", str(world), "--gpus", str(world),
+                           "--form", "native", "--workload", args.workload, "--reads", str(n), "--features", str(T),
+                           "--read-sets", str(n_sets), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+                    cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.native_timeout)
+                    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                    nat = json.loads(lines[-1]) if cp.returncode == 0 and lines else {
+                        "error": "native child rc %d: %s" % (cp.returncode, cp.stderr.strip()[-300:])}
+                else:
+                    nat = native_leg(nim, synth, torch, lib_obj, seqs, devs, n, L, n_sets, max(args.warmup, 3), args.steps)
+            except subprocess.TimeoutExpired:
+                nat = {"error": "native child: no result within %.0f s (stopped)" % args.native_timeout}
             except Exception as ex:  # the line of the torch form must not die with the second form
                 nat = {"error": str(ex)[:400]}
             out["native"] = nat

@@ -52,3 +52,15 @@ def test_bench_native_form_of_the_multi_gpu_step(extra):
     assert nat["parity_on_union"].startswith("bit-exact")
     assert nat["ranks"] == (3 if "--native-virtual" in extra else 1) and nat["rccl"] == ("--force-sharded" in extra)
     assert d["value"] == nat["reads_per_s"] and d["ms_per_step"] == nat["ms_per_step"]
+
+
+def test_bench_native_child_prints_the_native_object_alone():
+    """`--native-child N`: what rank 0 of a torch.distributed.run launch starts (as a process of its own, with a time limit) for
+    the native form -- here with three ranks sharing this box's GPU: one JSON object, the native leg's, parity-checked."""
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--native-child", "3", "--native-virtual", "3", "--gpus", "3",
+                         "--form", "native", "--steps", "4", "--warmup", "1", "--reads", "40000", "--features", "64"],
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert cp.returncode == 0, cp.stderr[-800:]
+    nat = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "error" not in nat and nat["ranks"] == 3 and nat["parity_on_union"].startswith("bit-exact")
+    assert nat["reads_per_s"] > 0 and "metric" not in nat
