@@ -276,6 +276,52 @@ def test_wide_classes_general_intersection_path():
     assert st["dynamic_classes"] > 0  # intersections that are not k-mer colours were interned on the device
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_lds_row_window_random_families(seed, monkeypatch):
+    """Randomised allele families around the limits of the LDS row window: family sizes on both sides of 256 rows, rows shifted
+    by a random number of singleton features (bitmaps that start anywhere relative to the 64-row words), divergence 0.5-3 %,
+    window caps at, below and above the longest bitmap, single-end and paired reads with and without tolerated mismatches."""
+    rng = np.random.default_rng(1000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    names, seqs = [], []
+    for k in range(int(rng.integers(0, 70))):
+        names.append("S%03d" % k)
+        seqs.append(acgt[rng.integers(0, 4, size=int(rng.integers(200, 400)))].tobytes().decode())
+    sizes = [int(rng.integers(257, 520)), int(rng.integers(65, 256)), int(rng.integers(300, 640))]
+    for fam, size in enumerate(sizes):
+        length = int(rng.integers(400, 700))
+        root = rng.integers(0, 4, size=length, dtype=np.uint8)
+        rate = float(rng.choice([0.005, 0.01, 0.03]))
+        for k in range(size):
+            a = root.copy()
+            if k:
+                m = rng.random(length) < rate
+                a[m] = (a[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
+            names.append("G%d*%03d" % (fam, k))
+            seqs.append(acgt[a].tobytes().decode())
+    words = (max(sizes) + 63 + 63) // 64
+    monkeypatch.setenv("NIMBLE_LDS_WINDOW_WORDS", str(int(rng.choice([words, words - 2, 5, 32]))))
+    case = Case(names, seqs, make_cfg(score_percent=0.2, score_threshold=30, max_hits_to_report=2000))
+    r1, r2 = [], []
+    for _ in range(1500):
+        f = int(rng.integers(0, len(seqs)))
+        s0 = seqs[f]
+        frag = int(rng.integers(150, min(len(s0), 380) + 1)) if len(s0) >= 150 else len(s0)
+        st = int(rng.integers(0, len(s0) - frag + 1))
+        a = np.frombuffer(s0[st:st + min(150, frag)].encode(), dtype=np.uint8).copy()
+        b = np.frombuffer(s0[st + frag - min(150, frag):st + frag].encode(), dtype=np.uint8).copy()[::-1]
+        b = np.frombuffer(b.tobytes().translate(bytes.maketrans(b"ACGT", b"TGCA")), dtype=np.uint8).copy()
+        for r in (a, b):
+            if rng.random() < 0.4:
+                r[int(rng.integers(0, len(r)))] = ord("ACGT"[int(rng.integers(0, 4))])
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+    b1, o1 = ora.pack_reads(r1)
+    b2, o2 = ora.pack_reads(r2)
+    case.check(b1, o1, cfg=case.cfg.copy(num_mismatches=0))
+    case.check(b1, o1, b2, o2, cfg=case.cfg.copy(num_mismatches=1))
+
+
 @pytest.mark.parametrize("sizes,n_reads,env", [
     ((150, 70, 150, 3), 8000, {}),
     ((500, 100, 20), 3000, {}),                                   # bitmaps of 9 words: the LDS row window
