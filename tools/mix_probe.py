@@ -27,12 +27,23 @@ CASES = [
     ("exact, every 4 consecutive reads identical", (1.0, 1.0, 1.0, 1.0), 0.0),
     ("low complexity (prefiltered)", (0.0, 0.0, 0.0, 1.0), 0.0),
     ("off-target, all reads identical", (0.0, 1.0, 1.0, 1.0), 0.0),
+    ("bench recipe, tiles of 256 sorted by differing bases", None, 0.005),
+    ("bench recipe, sorted by differing bases", None, 0.005),
 ]
 if os.environ.get("MIX_CASE"):
     CASES = [CASES[int(os.environ["MIX_CASE"])]]
 for tag, mix, subst in CASES:
     reads = synth.make_reads_torch(seqs, N, L=150, seed=synth.READ_SEED, device="cuda:0", mix=mix, subst=subst)
-    if "every 64" in tag:
+    if "sorted by differing" in tag:
+        # the same draw without substitutions differs from this one exactly in the substituted bases: order the reads by their
+        # number (off-target reads last) -- what a perfect predictor of a read's walk length could buy the tile partition
+        clean = synth.make_reads_torch(seqs, N, L=150, seed=synth.READ_SEED, device="cuda:0", mix=mix, subst=0.0)
+        d = (reads != clean).sum(1).clamp(max=7).to(torch.int64)
+        del clean
+        if "tiles" in tag:
+            d = d + 8 * (torch.arange(N, device="cuda:0") // 256)
+        reads = reads[torch.argsort(d, stable=True)].contiguous()
+    elif "every 64" in tag:
         reads = reads[::64].repeat_interleave(64, dim=0)[:N].contiguous()
     elif "every 4" in tag:
         reads = reads[::4].repeat_interleave(4, dim=0)[:N].contiguous()
