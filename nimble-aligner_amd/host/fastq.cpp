@@ -699,7 +699,7 @@ class ParallelGz {
           w->buf = std::move(nb);
           w->head = carry_.size();
         }
-        memcpy(w->buf.data() + w->head - carry_.size(), carry_.data(), carry_.size());
+        if (!carry_.empty()) memcpy(w->buf.data() + w->head - carry_.size(), carry_.data(), carry_.size());
         const size_t from = w->head - carry_.size();
         win_ = std::move(w);
         cur_.reset(new ParallelPlain(win_->buf.data(), from, win_->buf.size(), is_mate_, win_->final, pool_, packed_, stride_hint_));

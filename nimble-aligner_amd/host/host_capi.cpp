@@ -523,7 +523,7 @@ int nimble_host_pgzip_decompress(const char *path, int threads, const char *out_
       while (rd.next(p)) {
         buf.resize(p.size());
         parse::pgzip::resolve(p, buf.data());
-        fwrite(buf.data(), 1, buf.size(), f);
+        if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
         ++k;
       }
     } catch (...) {

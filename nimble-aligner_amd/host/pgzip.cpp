@@ -547,7 +547,7 @@ struct Reader::Impl {
     for (size_t i = 0; i < k; ++i) tail[i] = s[i] < SYM0 ? (uint8_t)s[i] : p.window[s[i] - SYM0];
     if (k == WSIZE) {
       window = tail;
-    } else {
+    } else if (k) {  // (a piece without output leaves the window as it is)
       memmove(window.data(), window.data() + k, WSIZE - k);
       memcpy(window.data() + WSIZE - k, tail.data(), k);
     }
