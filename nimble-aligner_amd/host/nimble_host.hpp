@@ -470,11 +470,25 @@ struct Record {
   bool aux_string(const char *tag, std::string &out) const;  // Aux::String (type Z) only
 };
 extern const char *const BAM_FIELDS_TO_REPORT[38];  // src/parse/bam.rs:9-49
+// A record by reference (the pipeline's own form): the body bytes -- everything behind block_size -- sit in an arena, and
+// what the grouping needs of the aux data was found in ONE walk over it when the record came in.  Every reported field is
+// formatted straight from these bytes when a row is written; no string is built per field and record.
+struct Raw {
+  uint32_t off = 0, len = 0;         // the body inside the arena
+  uint32_t aux = 0;                  // where the aux data starts inside the body
+  uint32_t cb = 0, cb_len = 0;       // value of CB:Z inside the body; cb_len = NONE: no such string tag
+  uint32_t umi = 0, umi_len = 0;     // value of UB:Z, else of UR:Z
+  uint8_t skip = 0;                  // SKIP_ALIGN as SortedBamReader pushes it: 0 = not pushed, 1 = "FALSE", 2 = "TRUE"
+  uint8_t qual_bad = 0;              // the quality bytes are no ASCII (0xFF = absent): reported once, the field reads empty
+  static constexpr uint32_t NONE = 0xFFFFFFFFu;
+};
 class Reader {
  public:
   explicit Reader(const std::string &path);
   ~Reader();
   bool next(Record &r);  // false at end of file; panics on a truncated record
+  // the same record appended to `arena` (body bytes only), aux offset set, tags not looked at yet
+  bool next_raw(std::vector<uint8_t> &arena, Raw &r);
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
@@ -483,7 +497,7 @@ class Reader {
 class SortedBamReader {
  public:
   SortedBamReader(const std::string &path, bool force_bam_paired);
-  bool next(Record &out);
+  bool next(Raw &out, const uint8_t *&arena);  // `arena` stays valid until the call that returns the first record of the next UMI
  private:
   void fill_buffer();
   void add_dummy_paired_reads();
@@ -491,9 +505,29 @@ class SortedBamReader {
   Reader reader_;
   bool force_bam_paired_;
   std::string current_umi_, next_umi_;
-  std::vector<Record> buffer_, next_records_;
+  std::vector<uint8_t> arena_, next_arena_;
+  std::vector<Raw> buffer_, next_records_;
   size_t cursor_ = 0;
 };
+// one (UMI, cell barcode) group of src/parse/bam.rs:51-288 by reference: records 2k / 2k + 1 are a pair
+struct UmiGroup {
+  std::vector<uint8_t> arena;
+  std::vector<Raw> recs;
+  std::string umi, cell;
+  void clear() {
+    arena.clear();
+    recs.clear();
+    umi.clear();
+    cell.clear();
+  }
+};
+// what the reference's UMIReader hands on per record, made from a Raw on demand (src/parse/bam.rs:139-254)
+inline size_t record_seq_len(const uint8_t *body) { int32_t v; memcpy(&v, body + 16, 4); return (size_t)(uint32_t)v; }
+inline bool record_is_reverse(const uint8_t *body) { return (body[14] & 0x10) != 0; }
+void raw_sequence(const uint8_t *body, const Raw &r, std::string &out);   // bases with the non-biological ones clipped, A/C/G/T
+void raw_quality(const uint8_t *body, const Raw &r, std::string &out);    // qualities in read direction, clipped alike
+void raw_fields(const uint8_t *body, const Raw &r, std::vector<std::string> &out);  // the 38 BAM_FIELDS_TO_REPORT values
+void raw_row_fields(const uint8_t *body, const Raw &r, std::string &out);  // the 36 written ones (no QUAL, no SEQ), tab-separated, appended
 // src/parse/bam.rs:51-288: one (UMI, cell barcode) group at a time: sequences with the non-biological bases clipped, and
 // the 38 reported fields per record
 class UMIReader {
@@ -503,14 +537,14 @@ class UMIReader {
   std::vector<std::string> current_umi_group;
   std::vector<std::vector<std::string>> current_metadata_group;
   std::string current_umi, current_cell_barcode;
+  // the same step without the strings: the group by reference (what process::bam::process takes)
+  bool next_group(UmiGroup &out);
  private:
-  bool get_umi_from_bam();
   SortedBamReader reader_;
   [[maybe_unused]] bool terminate_on_error_;  // the reference panics on every record error it meets, whatever this says
   size_t read_counter_ = 0;
-  std::vector<std::string> next_umi_group_;
-  std::vector<std::vector<std::string>> next_metadata_group_;
-  std::string next_umi_, next_cell_barcode_, current_iteration_key_, next_iteration_key_;
+  UmiGroup next_;
+  std::string current_iteration_key_, next_iteration_key_;
 };
 }  // namespace bam
 }  // namespace parse
