@@ -72,6 +72,7 @@ struct Reader::Impl {
   std::unique_ptr<Chunk> cur;
   size_t cur_at = 0;
   bool ended = false;
+  double waited = 0;  // the record decoder waiting for inflated data
   std::vector<uint8_t> buf;
 
   ~Impl() {
@@ -85,6 +86,8 @@ struct Reader::Impl {
     }
     if (fp) fclose(fp);
     if (f) gzclose(f);
+    if (getenv("NIMBLE_HOST_TIMING") && waited > 0)
+      fprintf(stderr, "[nimble host] bam reader: %.2f s waiting for inflated BGZF blocks\n", waited);
   }
 
   struct Member {
@@ -240,8 +243,10 @@ struct Reader::Impl {
         if (cur->last) ended = true;
       }
       if (ended) break;
+      const auto tw = std::chrono::steady_clock::now();
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return !queue.empty(); });
+      waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
       cur = std::move(queue.front());
       queue.pop_front();
       cur_at = 0;
@@ -321,6 +326,8 @@ bool Reader::next_raw(std::vector<uint8_t> &arena, Raw &r) {
   r.off = (uint32_t)at;
   r.len = (uint32_t)block;
   r.aux = (uint32_t)(o + (l_seq + 1) / 2 + l_seq);
+  r.l_seq = l_seq;
+  r.flag = (uint16_t)b_flag(p);
   return true;
 }
 
@@ -468,12 +475,55 @@ void raw_quality(const uint8_t *b, const Raw &r, std::string &out) {
   if (rev) std::reverse(out.begin(), out.end());
 }
 
+// The two of them as the call takes them (process/bam.rs:245-303): the read reverse-complemented back when the BAM holds its
+// reverse strand, the qualities in read direction -- written straight into the call's input arrays, two bases per packed byte
+// through a table (raw_sequence + utils::revcomp + raw_quality through strings took 750 ns a read).
+void raw_call_input(const uint8_t *b, const Raw &r, uint8_t *bases, uint8_t *quals) {
+  static const struct Tables {
+    uint8_t fwd[16], rc[16];
+    Tables() {
+      for (int c = 0; c < 16; ++c) {
+        const char ch = SEQ_CODE[c];
+        const char a = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? ch : 'A';
+        fwd[c] = (uint8_t)a;
+        rc[c] = (uint8_t)(a == 'A' ? 'T' : a == 'C' ? 'G' : a == 'G' ? 'C' : 'A');
+      }
+    }
+  } T;
+  const uint32_t l_seq = r.l_seq;
+  const bool rev = r.flag & 0x10;
+  uint32_t lo = 0, hi = l_seq;
+  if (l_seq == 124) {
+    if (rev) hi = l_seq - CLIP_LENGTH;
+    else lo = CLIP_LENGTH;
+  }
+  const uint8_t *sq = b + b_seq_at(b);
+  const uint8_t *q = sq + (l_seq + 1) / 2;
+  const uint32_t n = hi - lo;
+  if (!rev) {
+    for (uint32_t i = lo; i < hi; ++i) bases[i - lo] = T.fwd[(sq[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+    if (!r.qual_bad) memcpy(quals, q + lo, n);
+  } else {
+    // strip, then reverse-complement: base i of the kept stretch lands at n - 1 - (i - lo)
+    for (uint32_t i = lo; i < hi; ++i) bases[n - 1 - (i - lo)] = T.rc[(sq[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+    // (the qualities were reversed once by the reader, parse/bam.rs:270-287, and stay that way)
+    if (!r.qual_bad)
+      for (uint32_t i = lo; i < hi; ++i) quals[n - 1 - (i - lo)] = q[i];
+  }
+}
+
 namespace {
 inline void put_bool(std::string &o, bool v) { o += v ? "true" : "false"; }
-inline void put_int(std::string &o, long long v) {
+inline void put_int(std::string &o, long long v) {  // (snprintf took a microsecond per row: ten numbers a row)
   char tmp[24];
-  const int n = snprintf(tmp, sizeof tmp, "%lld", v);
-  o.append(tmp, (size_t)n);
+  char *e = tmp + sizeof tmp, *p = e;
+  unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+  do {
+    *--p = (char)('0' + u % 10);
+    u /= 10;
+  } while (u);
+  if (v < 0) *--p = '-';
+  o.append(p, (size_t)(e - p));
 }
 // field k of BAM_FIELDS_TO_REPORT appended to o; tags from one aux_walk over REPORT_TAGS.  (1 = QUAL and 15 = SEQ are made
 // by raw_quality / raw_sequence.)
@@ -511,6 +561,8 @@ inline void put_field(std::string &o, int k, const uint8_t *b, const Raw &r, con
   }
 }
 }  // namespace
+
+void append_int(std::string &o, long long v) { put_int(o, v); }
 
 void raw_fields(const uint8_t *b, const Raw &r, std::vector<std::string> &out) {
   uint32_t tat[15], tlen[15];
@@ -669,18 +721,40 @@ bool SortedBamReader::next(Raw &out, const uint8_t *&arena) {
 UMIReader::UMIReader(const std::string &path, bool terminate_on_error, bool force_bam_paired)
     : reader_(path, force_bam_paired), terminate_on_error_(terminate_on_error) {}
 
-// the group of the step before (`next_`, opened by the record that ended the group before it) grows until a record of
-// another (UMI, cell barcode) shows up; false = the input ended (the group is the last one)
-bool UMIReader::next_group(UmiGroup &cur) {
-  cur.clear();
-  std::swap(cur, next_);
+std::string UmiBatch::umi_of(size_t g) const {
+  if (groups[g].count == 0) return std::string();
+  const Raw &r = recs[groups[g].first];
+  return std::string(reinterpret_cast<const char *>(arena.data() + r.off + r.umi), r.umi_len);
+}
+std::string UmiBatch::cell_of(size_t g) const {
+  if (groups[g].count == 0) return std::string();
+  const Raw &r = recs[groups[g].first + groups[g].count - 1];
+  return std::string(reinterpret_cast<const char *>(arena.data() + r.off + r.cb), r.cb_len >= 2 ? r.cb_len - 2 : 0);
+}
+
+// A group starts with the record that ended the group before it (kept aside) and grows until a record of another (UMI, cell
+// barcode) shows up; false = the input ended (the group is the last one).
+bool UMIReader::next_group(UmiBatch &st) {
+  UmiBatch::Group g;
+  g.first = (uint32_t)st.recs.size();
+  auto take = [&](const uint8_t *b, Raw rec) {
+    rec.off = (uint32_t)st.arena.size();
+    st.arena.insert(st.arena.end(), b, b + rec.len);
+    st.recs.push_back(rec);
+    ++g.count;
+  };
+  if (have_pend_) {
+    take(pend_bytes_.data(), pend_);
+    have_pend_ = false;
+  }
   current_iteration_key_ = next_iteration_key_;
   next_iteration_key_.clear();
   Raw rec;
   const uint8_t *A = nullptr;
   std::string key;
+  bool more = false;
   for (;;) {
-    if (!reader_.next(rec, A)) return false;
+    if (!reader_.next(rec, A)) break;
     ++read_counter_;
     if (read_counter_ % 1000000 == 0) printf("Aligned reads %zu-%zu\n", read_counter_ - 1000000, read_counter_);
     const uint8_t *b = A + rec.off;
@@ -690,45 +764,42 @@ bool UMIReader::next_group(UmiGroup &cur) {
     const size_t cell_len = rec.cb_len >= 2 ? rec.cb_len - 2 : 0;
     key.assign(um, rec.umi_len);
     key.append(cb, cell_len);
-    if (cur.umi.empty()) cur.umi.assign(um, rec.umi_len);
     if (current_iteration_key_.empty()) current_iteration_key_ = key;
     // the quality string has to be text: Phred bytes are 0..93, anything else (0xFF = absent) is no ASCII
     {
       const uint32_t l_seq = b_lseq(b);
       const uint8_t *q = b + b_seq_at(b) + (l_seq + 1) / 2;
-      bool bad = false;
-      for (uint32_t i = 0; i < l_seq; ++i) bad |= q[i] >= 0x80;
-      if (bad) {
+      uint8_t any = 0;
+      for (uint32_t i = 0; i < l_seq; ++i) any |= q[i];
+      if (any & 0x80) {
         puts("QUAL parsing warning: invalid utf-8 sequence");
         rec.qual_bad = 1;
       }
     }
-    UmiGroup &g = current_iteration_key_ == key ? cur : next_;
-    const uint32_t at = (uint32_t)g.arena.size();
-    g.arena.insert(g.arena.end(), b, b + rec.len);
-    rec.off = at;
-    g.recs.push_back(rec);
-    if (&g == &cur) {
-      cur.cell.assign(cb, cell_len);
+    if (current_iteration_key_ == key) {
+      take(b, rec);
     } else {
-      next_.umi.assign(um, rec.umi_len);
-      next_.cell.assign(cb, cell_len);
+      pend_bytes_.assign(b, b + rec.len);
+      pend_ = rec;
+      have_pend_ = true;
       next_iteration_key_ = key;
-      return true;
+      more = true;
+      break;
     }
   }
+  st.groups.push_back(g);
+  return more;
 }
 
 bool UMIReader::next() {  // true = that was the final UMI
-  UmiGroup g;
-  const bool more = next_group(g);
-  current_umi = g.umi;
-  current_cell_barcode = g.cell;
-  current_umi_group.assign(g.recs.size(), std::string());
-  current_metadata_group.assign(g.recs.size(), std::vector<std::string>());
-  for (size_t i = 0; i < g.recs.size(); ++i) {
-    const uint8_t *b = g.arena.data() + g.recs[i].off;
-    raw_fields(b, g.recs[i], current_metadata_group[i]);
+  UmiBatch st;
+  const bool more = next_group(st);
+  current_umi = st.umi_of(0);
+  current_cell_barcode = st.cell_of(0);
+  current_umi_group.assign(st.recs.size(), std::string());
+  current_metadata_group.assign(st.recs.size(), std::vector<std::string>());
+  for (size_t i = 0; i < st.recs.size(); ++i) {
+    raw_fields(st.arena.data() + st.recs[i].off, st.recs[i], current_metadata_group[i]);
     current_umi_group[i] = current_metadata_group[i][15];
   }
   return !more;
@@ -775,6 +846,7 @@ std::string bam_header(const char *prefix) {
 class GzWriter {
  public:
   GzWriter(const std::string &path, unsigned threads) {
+    if (const char *e = getenv("NIMBLE_GZIP_LEVEL")) level_ = std::min(9, std::max(1, atoi(e)));
     f_ = fopen(path.c_str(), "wb");
     if (!f_) throw Panic("could not create " + path);
     static const unsigned char head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
@@ -837,7 +909,7 @@ class GzWriter {
       }
       z_stream z;
       memset(&z, 0, sizeof z);
-      bool ok = deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+      bool ok = deflateInit2(&z, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
       if (ok) {
         j->out.resize(deflateBound(&z, (uLong)j->text.size()) + 16);
         z.next_in = (Bytef *)j->text.data();
@@ -868,6 +940,7 @@ class GzWriter {
     }
   }
   FILE *f_ = nullptr;
+  int level_ = 6;  // flate2's Compression::default()
   std::string cur_;
   std::vector<std::unique_ptr<Job>> jobs_;
   std::vector<std::thread> workers_;
@@ -879,7 +952,31 @@ class GzWriter {
   bool stop_ = false, failed_ = false;
 };
 
-using Group = parse::bam::UmiGroup;  // one UMI x cell barcode: records 2k / 2k + 1 are a pair
+
+// a host buffer that keeps its size from batch to batch and is page-locked for the device's copy engine (pageable memory goes
+// through the runtime's bounce buffers: 58 MB of bases and qualities per batch took 12 of a call's 16 ms)
+struct PinBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  uint8_t *ensure(size_t n) {
+    if (n <= cap) return p;
+    release();
+    cap = n + n / 4 + (1u << 20);
+    p = static_cast<uint8_t *>(malloc(cap));
+    if (!p) throw Panic("out of memory");
+    pinned = nimble_pinned_register(p, cap) == 0;
+    return p;
+  }
+  void release() {
+    if (p && pinned) nimble_pinned_unregister(p);
+    free(p);
+    p = nullptr;
+    cap = 0;
+    pinned = false;
+  }
+  ~PinBuf() { release(); }
+};
 
 // body of a parallel loop over [0, n): `threads` workers take indices from a shared counter
 template <class F>
@@ -940,64 +1037,60 @@ void process(const std::vector<std::string> &input_files,
   // UMI groups are gathered into batches: one device call per batch and library, the group index is the segment
   size_t batch_pairs = 1u << 17;  // (small enough that the reader thread and the consumer overlap on ordinary files)
   if (const char *e = getenv("NIMBLE_BAM_BATCH")) batch_pairs = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1);
-  std::vector<Group> groups;
+  parse::bam::UmiBatch store;
   size_t pairs = 0;
 
-  double t_prep = 0, t_call = 0, t_rows = 0;
+  double t_prep = 0, t_call = 0, t_rows = 0, t_write = 0, t_free = 0;
+  PinBuf b_mem[2], q_mem[2];
   const unsigned row_threads = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
   auto flush = [&]() {
-    if (groups.empty()) return;
+    if (store.groups.empty()) return;
+    const size_t n_groups = store.groups.size();
+    const uint8_t *const arena = store.arena.data();
     const auto tp0 = std::chrono::steady_clock::now();
     // the call's inputs: R1 = record 2k, R2 = record 2k + 1, each reverse-complemented when the BAM says the read was
     // (process/bam.rs:245-303); the quality strings are already in read direction (parse/bam.rs:270-287).  Lengths first
     // (one pass), then every pair's bases and qualities written into place by several threads.
-    std::vector<uint8_t> b[2], q[2], skip[2];
+    uint8_t *b[2] = {nullptr, nullptr}, *q[2] = {nullptr, nullptr};  // (not zero-filled: every byte is written below)
+    std::vector<uint8_t> skip[2];
     std::vector<uint64_t> off[2] = {{0}, {0}};
     std::vector<uint32_t> seg;
-    std::vector<size_t> first_pair(groups.size() + 1, 0);
-    std::vector<std::pair<uint32_t, uint32_t>> where;  // pair -> (group, first record)
+    std::vector<size_t> first_pair(n_groups + 1, 0);
+    std::vector<uint32_t> where;  // pair -> its first record
     uint32_t max_len = 1;
-    for (size_t g = 0; g < groups.size(); ++g) {
-      const Group &G = groups[g];
+    for (size_t g = 0; g < n_groups; ++g) {
+      const parse::bam::UmiBatch::Group &G = store.groups[g];
       first_pair[g] = seg.size();
-      for (size_t k = 0; k + 1 < G.recs.size(); k += 2) {
+      for (size_t k = 0; k + 1 < G.count; k += 2) {
         for (int m = 0; m < 2; ++m) {
-          const uint8_t *body = G.arena.data() + G.recs[k + m].off;
-          const uint32_t l_seq = (uint32_t)parse::bam::record_seq_len(body);
-          const uint32_t len = l_seq == 124 ? l_seq - 13 : l_seq;
-          if (G.recs[k + m].qual_bad && len != 0) {
+          const parse::bam::Raw &R = store.recs[G.first + k + (size_t)m];
+          const uint32_t len = R.l_seq == 124 ? R.l_seq - 13 : R.l_seq;
+          if (R.qual_bad && len != 0) {
             std::vector<std::string> md;
-            parse::bam::raw_fields(body, G.recs[k + m], md);
+            parse::bam::raw_fields(arena + R.off, R, md);
             throw Panic("BAM record without usable qualities (" + md[0] + "): not supported by the MI355X build");
           }
           off[m].push_back(off[m].back() + len);
           max_len = std::max<uint32_t>(max_len, len);
         }
         seg.push_back((uint32_t)g);
-        where.emplace_back((uint32_t)g, (uint32_t)k);
+        where.push_back(G.first + (uint32_t)k);
       }
     }
-    first_pair[groups.size()] = seg.size();
+    first_pair[n_groups] = seg.size();
     const uint64_t n = seg.size();
     for (int m = 0; m < 2; ++m) {
-      b[m].resize(off[m].back());
-      q[m].resize(off[m].back());
+      b[m] = b_mem[m].ensure(off[m].back() + 1);
+      q[m] = q_mem[m].ensure(off[m].back() + 1);
       skip[m].resize(n);
     }
     {
       const size_t CH = 4096;
       parallel_indices((n + CH - 1) / CH, row_threads, [&](size_t c) {
-        std::string s, ql;
         for (size_t i = c * CH; i < std::min<size_t>(n, (c + 1) * CH); ++i) {
-          const Group &G = groups[where[i].first];
           for (int m = 0; m < 2; ++m) {
-            const parse::bam::Raw &R = G.recs[where[i].second + (size_t)m];
-            const uint8_t *body = G.arena.data() + R.off;
-            parse::bam::raw_sequence(body, R, s);
-            if (parse::bam::record_is_reverse(body)) s = utils::revcomp(s);
-            parse::bam::raw_quality(body, R, ql);
-            memcpy(b[m].data() + off[m][i], s.data(), s.size());
-            memcpy(q[m].data() + off[m][i], ql.data(), ql.size());
+            const parse::bam::Raw &R = store.recs[where[i] + (size_t)m];
+            parse::bam::raw_call_input(arena + R.off, R, b[m] + off[m][i], q[m] + off[m][i]);
             skip[m][i] = R.skip == 2 ? 1 : 0;
           }
         }
@@ -1005,19 +1098,19 @@ void process(const std::vector<std::string> &input_files,
     }
     for (size_t lib = 0; lib < n_lib && n; ++lib) {
       align::ReadBatch a, m;
-      a.bases = b[0].data();
+      a.bases = b[0];
       a.offsets = off[0].data();
       a.n = n;
       a.max_len = max_len;
-      m.bases = b[1].data();
+      m.bases = b[1];
       m.offsets = off[1].data();
       m.n = n;
       m.max_len = max_len;
       align::UmiExtras ex;
       ex.segment = seg.data();
-      ex.n_segments = (uint32_t)groups.size();
-      ex.qual[0] = q[0].data();
-      ex.qual[1] = q[1].data();
+      ex.n_segments = (uint32_t)n_groups;
+      ex.qual[0] = q[0];
+      ex.qual[1] = q[1];
       ex.skip[0] = skip[0].data();
       ex.skip[1] = skip[1].data();
       const auto tc0 = std::chrono::steady_clock::now();
@@ -1033,59 +1126,90 @@ void process(const std::vector<std::string> &input_files,
       } rows_lap{t_rows, tr0};
       // rows of a group (res.rows is sorted by segment): the groups are independent, their text is made by several threads
       // and written in group order
-      std::vector<size_t> row_first(groups.size() + 1, 0);
+      std::vector<size_t> row_first(n_groups + 1, 0);
       {
         size_t row = 0;
-        for (size_t g = 0; g < groups.size(); ++g) {
+        for (size_t g = 0; g < n_groups; ++g) {
           row_first[g] = row;
           while (row < res.rows.size() && res.rows[row].segment == (uint32_t)g) ++row;
         }
-        row_first[groups.size()] = row;
+        row_first[n_groups] = row;
       }
       const size_t GCH = 256;  // groups per piece of text
-      std::vector<std::string> text((groups.size() + GCH - 1) / GCH);
+      std::vector<std::string> text((n_groups + GCH - 1) / GCH);
       parallel_indices(text.size(), row_threads, [&](size_t piece) {
         std::string &line = text[piece];
-        for (size_t g = piece * GCH; g < std::min(groups.size(), (piece + 1) * GCH); ++g) {
-          const Group &G = groups[g];
+        std::vector<uint32_t> last;                          // (made once per piece, not per group: most groups are a pair or two)
+        std::vector<std::pair<const char *, uint32_t>> scored;  // QNAMEs of the reads that stand for a callset
+        std::string f;
+        for (size_t g = piece * GCH; g < std::min(n_groups, (piece + 1) * GCH); ++g) {
+          const parse::bam::Raw *const recs = store.recs.data() + store.groups[g].first;
           const size_t p0 = first_pair[g], np = first_pair[g + 1] - p0;
           const size_t row0 = row_first[g], row1 = row_first[g + 1];
           if (row1 == row0) continue;  // `if s.len() == 0 { results.push(vec![]) }`: nothing at all for this UMI
           // filter_reasons is keyed by the read key (R1 string + R2 string): a later pair with the same key replaces an
           // earlier one (align.rs:591-600)
-          std::unordered_map<std::string, size_t> last_of_key;
-          auto key_of = [&](size_t pair) {
-            const uint64_t i = p0 + pair;
-            return std::string(b[0].begin() + (long)off[0][i], b[0].begin() + (long)off[0][i + 1]) +
-                   std::string(b[1].begin() + (long)off[1][i], b[1].begin() + (long)off[1][i + 1]);
+          // last[k] = the last pair of the group with pair k's key
+          last.assign(np, 0u);
+          auto same_key = [&](size_t x, size_t y) {
+            const uint64_t i = p0 + x, j = p0 + y;
+            const uint64_t a0 = off[0][i + 1] - off[0][i], a1 = off[1][i + 1] - off[1][i];
+            // (the key is the concatenation R1 + R2: equal as strings, not mate by mate -- compare it as one)
+            if (a0 + a1 != (off[0][j + 1] - off[0][j]) + (off[1][j + 1] - off[1][j])) return false;
+            if (a0 == off[0][j + 1] - off[0][j])
+              return memcmp(b[0] + off[0][i], b[0] + off[0][j], a0) == 0 && memcmp(b[1] + off[1][i], b[1] + off[1][j], a1) == 0;
+            std::string kx(reinterpret_cast<const char *>(b[0] + off[0][i]), a0), ky(reinterpret_cast<const char *>(b[0] + off[0][j]), off[0][j + 1] - off[0][j]);
+            kx.append(reinterpret_cast<const char *>(b[1] + off[1][i]), a1);
+            ky.append(reinterpret_cast<const char *>(b[1] + off[1][j]), off[1][j + 1] - off[1][j]);
+            return kx == ky;
           };
-          for (size_t k = 0; k < np; ++k) last_of_key[key_of(k)] = k;
+          if (np <= 48) {
+            for (size_t k = 0; k < np; ++k) {
+              uint32_t l = (uint32_t)k;
+              for (size_t j = np; j-- > k + 1;)
+                if (same_key(k, j)) {
+                  l = (uint32_t)j;
+                  break;
+                }
+              last[k] = l;
+            }
+          } else {
+            std::unordered_map<std::string, uint32_t> last_of_key;
+            auto key_of = [&](size_t pair) {
+              const uint64_t i = p0 + pair;
+              std::string k(reinterpret_cast<const char *>(b[0] + off[0][i]), off[0][i + 1] - off[0][i]);
+              k.append(reinterpret_cast<const char *>(b[1] + off[1][i]), off[1][i + 1] - off[1][i]);
+              return k;
+            };
+            for (size_t k = 0; k < np; ++k) last_of_key[key_of(k)] = (uint32_t)k;
+            for (size_t k = 0; k < np; ++k) last[k] = last_of_key.at(key_of(k));
+          }
           auto qname_of = [&](size_t rec) {
-            const uint8_t *body = G.arena.data() + G.recs[rec].off;
+            const uint8_t *body = arena + recs[rec].off;
             const uint32_t ln = body[8];
-            return std::string(reinterpret_cast<const char *>(body + 32), ln ? ln - 1 : 0);
+            return std::make_pair(reinterpret_cast<const char *>(body + 32), ln ? ln - 1 : 0u);
           };
-          std::unordered_set<std::string> scored_qnames;
+          scored.clear();
           auto emit = [&](const std::string &features, int32_t count, size_t pair) {
-            const parse::bam::Raw &m1 = G.recs[2 * pair], &m2 = G.recs[2 * pair + 1];
-            const align::FilterRecord &fr = res.per_read[p0 + last_of_key.at(key_of(pair))];
+            const parse::bam::Raw &m1 = recs[2 * pair], &m2 = recs[2 * pair + 1];
+            const align::FilterRecord &fr = res.per_read[p0 + last[pair]];
             line += features;
             line += '\t';
-            line += std::to_string(count);
+            parse::bam::append_int(line, count);
             line += '\t';
-            parse::bam::raw_row_fields(G.arena.data() + m2.off, m2, line);
+            parse::bam::raw_row_fields(arena + m2.off, m2, line);
             line += '\t';
-            parse::bam::raw_row_fields(G.arena.data() + m1.off, m1, line);
+            parse::bam::raw_row_fields(arena + m1.off, m1, line);
             line += '\t';
             line += align::to_string(fr.r2);  // "r1": the mate
             line += '\t';
-            line += std::to_string(fr.score2);
+            parse::bam::append_int(line, fr.score2);
             line += '\t';
             line += align::to_string(align::FilterReason::None);
             line += "\t0\t";
             line += align::to_string(fr.r1);  // "r2": the first read
             line += '\t';
-            line += std::to_string(fr.score1);
+            parse::bam::append_int(line, fr.score1);
             line += '\t';
             line += align::to_string(align::FilterReason::None);
             line += "\t0\t";
@@ -1095,21 +1219,31 @@ void process(const std::vector<std::string> &input_files,
           for (size_t r = row0; r < row1; ++r) {
             const align::UmiRow &R = res.rows[r];
             const size_t pair = R.representative - p0;
-            scored_qnames.insert(qname_of(2 * pair));  // score.1.1[0]: the first read's QNAME
-            std::string f;
-            for (size_t t = 0; t < R.features.size(); ++t) f += (t ? "," : "") + R.features[t];
+            scored.push_back(qname_of(2 * pair));  // score.1.1[0]: the first read's QNAME
+            f.clear();
+            for (size_t t = 0; t < R.features.size(); ++t) {
+              if (t) f += ',';
+              f += R.features[t];
+            }
             emit(f, R.count, pair);
           }
           for (size_t k = 0; k < np; ++k) {  // pairs that stand for no callset: an empty call (process/bam.rs:341-355)
-            if (scored_qnames.count(qname_of(2 * k + 1))) continue;
+            const auto qn = qname_of(2 * k + 1);
+            bool is_scored = false;
+            for (const auto &sq : scored) is_scored |= sq.second == qn.second && memcmp(sq.first, qn.first, qn.second) == 0;
+            if (is_scored) continue;
             emit("", 0, k);
           }
         }
       });
+      const auto tw0 = std::chrono::steady_clock::now();
       for (const std::string &t : text)
         if (!t.empty()) write_line(lib, t);
+      t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
     }
-    groups.clear();
+    const auto tf0 = std::chrono::steady_clock::now();
+    store.clear();
+    t_free += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
     pairs = 0;
   };
 
@@ -1118,7 +1252,7 @@ void process(const std::vector<std::string> &input_files,
   // overlap the device call and the writing of the batch before.
   puts("Spawning reader thread.");
   struct Batch {
-    std::vector<Group> groups;
+    parse::bam::UmiBatch store;
     std::string error;
     bool last = false;
   };
@@ -1147,15 +1281,18 @@ void process(const std::vector<std::string> &input_files,
       parse::bam::UMIReader reader(input_files.at(0), false, force_bam_paired);
       bool has_aligned = false;
       for (;;) {
-        Group g;
-        const bool final_umi = !reader.next_group(g);
+        const bool final_umi = !reader.next_group(cur->store);
         if (final_umi && has_aligned) {
+          // (the group just read is the file's last: collected, never sent -- process/bam.rs:163-178)
+          const parse::bam::UmiBatch::Group last = cur->store.groups.back();
+          cur->store.groups.pop_back();
+          cur->store.recs.resize(last.first);
           puts("Finished reading UMIs from input file.");
           break;
         }
-        cur_pairs += g.recs.size() / 2;
-        cur->groups.push_back(std::move(g));
-        if (cur_pairs >= batch_pairs && !push(false)) return;
+        cur_pairs += cur->store.groups.back().count / 2;
+        // (record offsets are 32-bit: a batch is closed well before its arena reaches that)
+        if ((cur_pairs >= batch_pairs || cur->store.arena.size() > (1ull << 31)) && !push(false)) return;
         has_aligned = true;
       }
       t_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1179,7 +1316,7 @@ void process(const std::vector<std::string> &input_files,
       qcv.notify_all();
       const auto tf = std::chrono::steady_clock::now();
       t_wait += std::chrono::duration<double>(tf - tw).count();
-      groups = std::move(bt->groups);
+      store = std::move(bt->store);
       flush();
       t_flush += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
       if (!bt->error.empty()) failure = bt->error;
@@ -1198,8 +1335,9 @@ void process(const std::vector<std::string> &input_files,
   if (!failure.empty()) throw Panic(failure);
   if (getenv("NIMBLE_HOST_TIMING"))
     fprintf(stderr, "[nimble host] bam pipeline: reader thread %.2f s (BGZF, records, UMI groups); consumer %.2f s waiting for it, "
-            "%.2f s in calls and rows (%.2f preparing the calls' inputs, %.2f in the calls, %.2f writing rows)\n", t_read, t_wait,
-            t_flush, t_prep, t_call, t_rows);
+            "%.2f s in calls and rows (%.2f preparing the calls' inputs, %.2f in the calls, %.2f making and writing rows, of which "
+            "%.2f handing them to the gzip writer; %.2f freeing the batch)\n", t_read, t_wait, t_flush, t_prep, t_call, t_rows, t_write,
+            t_free);
   for (size_t i = 0; i < n_lib; ++i) {
     if (out[i]->close()) printf("Successfully flushed and closed file %zu\n", i);
     else fprintf(stderr, "Error finishing GZIP for file %zu\n", i);

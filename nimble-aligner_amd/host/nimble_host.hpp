@@ -478,6 +478,8 @@ struct Raw {
   uint32_t aux = 0;                  // where the aux data starts inside the body
   uint32_t cb = 0, cb_len = 0;       // value of CB:Z inside the body; cb_len = NONE: no such string tag
   uint32_t umi = 0, umi_len = 0;     // value of UB:Z, else of UR:Z
+  uint32_t l_seq = 0;                // bases of the record (kept here: the call's inputs are sized without touching the bodies)
+  uint16_t flag = 0;
   uint8_t skip = 0;                  // SKIP_ALIGN as SortedBamReader pushes it: 0 = not pushed, 1 = "FALSE", 2 = "TRUE"
   uint8_t qual_bad = 0;              // the quality bytes are no ASCII (0xFF = absent): reported once, the field reads empty
   static constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -509,17 +511,25 @@ class SortedBamReader {
   std::vector<Raw> buffer_, next_records_;
   size_t cursor_ = 0;
 };
-// one (UMI, cell barcode) group of src/parse/bam.rs:51-288 by reference: records 2k / 2k + 1 are a pair
-struct UmiGroup {
+// (UMI, cell barcode) groups of src/parse/bam.rs:51-288 by reference, many of them in ONE arena and ONE record array (a group
+// of its own vectors cost two allocations made by the reader thread and freed by the consumer: half a million groups of a
+// 4 M-pair file took the consumer a second to free).  Records 2k / 2k + 1 of a group are a pair.
+struct UmiBatch {
   std::vector<uint8_t> arena;
   std::vector<Raw> recs;
-  std::string umi, cell;
+  struct Group {
+    uint32_t first = 0, count = 0;  // in recs
+  };
+  std::vector<Group> groups;
   void clear() {
     arena.clear();
     recs.clear();
-    umi.clear();
-    cell.clear();
+    groups.clear();
   }
+  // the reference's current_umi / current_cell_barcode of group g: the UMI of its first record, the cell barcode (CB without
+  // its last two characters) of its last
+  std::string umi_of(size_t g) const;
+  std::string cell_of(size_t g) const;
 };
 // what the reference's UMIReader hands on per record, made from a Raw on demand (src/parse/bam.rs:139-254)
 inline size_t record_seq_len(const uint8_t *body) { int32_t v; memcpy(&v, body + 16, 4); return (size_t)(uint32_t)v; }
@@ -527,7 +537,9 @@ inline bool record_is_reverse(const uint8_t *body) { return (body[14] & 0x10) !=
 void raw_sequence(const uint8_t *body, const Raw &r, std::string &out);   // bases with the non-biological ones clipped, A/C/G/T
 void raw_quality(const uint8_t *body, const Raw &r, std::string &out);    // qualities in read direction, clipped alike
 void raw_fields(const uint8_t *body, const Raw &r, std::vector<std::string> &out);  // the 38 BAM_FIELDS_TO_REPORT values
-void raw_row_fields(const uint8_t *body, const Raw &r, std::string &out);  // the 36 written ones (no QUAL, no SEQ), tab-separated, appended
+void raw_row_fields(const uint8_t *body, const Raw &r, std::string &out);
+void raw_call_input(const uint8_t *body, const Raw &r, uint8_t *bases, uint8_t *quals);  // the read as the call takes it
+void append_int(std::string &out, long long v);  // the 36 written ones (no QUAL, no SEQ), tab-separated, appended
 // src/parse/bam.rs:51-288: one (UMI, cell barcode) group at a time: sequences with the non-biological bases clipped, and
 // the 38 reported fields per record
 class UMIReader {
@@ -537,13 +549,17 @@ class UMIReader {
   std::vector<std::string> current_umi_group;
   std::vector<std::vector<std::string>> current_metadata_group;
   std::string current_umi, current_cell_barcode;
-  // the same step without the strings: the group by reference (what process::bam::process takes)
-  bool next_group(UmiGroup &out);
+  // the same step without the strings: the group appended to `out` by reference (what process::bam::process takes); false =
+  // the input ended with this group
+  bool next_group(UmiBatch &out);
  private:
   SortedBamReader reader_;
   [[maybe_unused]] bool terminate_on_error_;  // the reference panics on every record error it meets, whatever this says
   size_t read_counter_ = 0;
-  UmiGroup next_;
+  // the record that ended the group before: the first of the next group
+  std::vector<uint8_t> pend_bytes_;
+  Raw pend_;
+  bool have_pend_ = false;
   std::string current_iteration_key_, next_iteration_key_;
 };
 }  // namespace bam
