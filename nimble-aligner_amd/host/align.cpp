@@ -820,28 +820,35 @@ UmiOutput get_calls_umis(const ReadBatch &seqs, const ReadBatch *mates, const Um
     return id;
   };
   UmiOutput out;
-  // entries arrive sorted by (segment, c1, c2): fold each segment's class pairs into callsets
+  out.callsets = &memo.callsets;
+  // entries arrive sorted by (segment, c1, c2): fold each segment's class pairs into callsets (a handful per segment: a
+  // small array, no map, and no copy of the feature names per row -- 131 k segments a call made this the call's longest part)
+  std::vector<std::pair<int32_t, std::pair<int64_t, uint32_t>>> acc;  // callset id -> (count, representative)
   for (uint64_t e = 0; e < ne;) {
     const uint32_t seg = sg[e];
-    std::map<int32_t, std::pair<int64_t, uint32_t>> acc;  // callset id -> (count, representative)
+    acc.clear();
     for (; e < ne && sg[e] == seg; ++e) {
       const int32_t id = callset_of(c1[e], c2[e]);
       if (id < 0) continue;
-      auto &slot = acc[id];
-      slot.first += (int64_t)cnt[e];
-      slot.second = std::max(slot.second, rep[e]);
+      size_t k = 0;
+      while (k < acc.size() && acc[k].first != id) ++k;
+      if (k == acc.size()) acc.push_back({id, {0, 0u}});
+      acc[k].second.first += (int64_t)cnt[e];
+      acc[k].second.second = std::max(acc[k].second.second, rep[e]);
     }
     const size_t first = out.rows.size();
     for (auto &kv : acc) {
       UmiRow r;
       r.segment = seg;
-      r.features = memo.callsets[(size_t)kv.first];
+      r.callset = kv.first;
       r.count = (int32_t)kv.second.first;
       r.representative = kv.second.second;
-      out.rows.push_back(std::move(r));
+      out.rows.push_back(r);
     }
-    std::sort(out.rows.begin() + (long)first, out.rows.end(),
-              [](const UmiRow &a, const UmiRow &b) { return a.features < b.features; });
+    if (out.rows.size() - first > 1)
+      std::sort(out.rows.begin() + (long)first, out.rows.end(), [&](const UmiRow &a, const UmiRow &b) {
+        return memo.callsets[(size_t)a.callset] < memo.callsets[(size_t)b.callset];
+      });
   }
   if (want_per_read) {
     const uint64_t n = seqs.n;

@@ -261,7 +261,7 @@ int nimble_score_call_umis(nimble_library *l, const uint8_t *r1, const uint64_t 
     }
     std::unique_ptr<nimble_umi_rows> r(new nimble_umi_rows());
     r->out = align::get_calls_umis(b1, r2 ? &b2 : nullptr, ex, *l->index, l->ref, l->cfg, want_per_read != 0);
-    for (auto &row : r->out.rows) r->joined.push_back(join_tab(row.features));
+    for (auto &row : r->out.rows) r->joined.push_back(join_tab(r->out.features(row)));
     *out = r.release();
   });
 }

@@ -224,12 +224,15 @@ struct UmiExtras {
 };
 struct UmiRow {
   uint32_t segment;
-  std::vector<std::string> features;
+  int32_t callset;  // index into UmiOutput::callsets (a row does not carry a copy of its feature names)
   int32_t count;
   uint32_t representative;  // a read of this callset (the reference keeps one read's BAM fields per callset)
 };
 struct UmiOutput {
   std::vector<UmiRow> rows;           // sorted by (segment, callset)
+  // the feature lists the rows refer to: the index's memo for (reference, config), which outlives the output and only grows
+  const std::vector<std::vector<std::string>> *callsets = nullptr;
+  const std::vector<std::string> &features(const UmiRow &r) const { return (*callsets)[(size_t)r.callset]; }
   std::vector<FilterRecord> per_read;  // when requested
 };
 UmiOutput get_calls_umis(const ReadBatch &sequences, const ReadBatch *mate_sequences, const UmiExtras &extras,
@@ -539,6 +542,7 @@ void raw_quality(const uint8_t *body, const Raw &r, std::string &out);    // qua
 void raw_fields(const uint8_t *body, const Raw &r, std::vector<std::string> &out);  // the 38 BAM_FIELDS_TO_REPORT values
 void raw_row_fields(const uint8_t *body, const Raw &r, std::string &out);
 void raw_call_input(const uint8_t *body, const Raw &r, uint8_t *bases, uint8_t *quals);  // the read as the call takes it
+bool raw_quality_is_text(const uint8_t *body, const Raw &r);  // no byte above 0x7F (the reference needs the qualities as UTF-8)
 void append_int(std::string &out, long long v);  // the 36 written ones (no QUAL, no SEQ), tab-separated, appended
 // src/parse/bam.rs:51-288: one (UMI, cell barcode) group at a time: sequences with the non-biological bases clipped, and
 // the 38 reported fields per record

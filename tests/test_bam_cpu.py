@@ -63,7 +63,12 @@ def make_records(rng, n_umis=40, seq_of=None, orphan_only_umi=False, good_quals=
 
 @pytest.mark.parametrize("force", [False, True])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_umi_groups_equal_the_model(tmp_path, force, seed):
+@pytest.mark.parametrize("batch", [0, 2048, 9000])
+def test_umi_groups_equal_the_model(tmp_path, force, seed, batch, monkeypatch):
+    """batch: compressed bytes the BGZF reader inflates at once (0 = its own 4 MiB): with a few KB, records -- and their
+    size fields -- straddle the batches, whose whole records the inflate helpers describe ahead of the decoder."""
+    if batch:
+        monkeypatch.setenv("NIMBLE_BGZF_BATCH", str(batch))
     rng = np.random.default_rng(seed)
     recs = make_records(rng, n_umis=60 if seed != 3 else 1, orphan_only_umi=seed == 2)
     path = str(tmp_path / "t.bam")

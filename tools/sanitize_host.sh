@@ -35,6 +35,6 @@ g++ -shared $FLAGS -o $OUT/lib/libnimble_host.so $OBJS -L$OUT/lib -lnimble_hip -
 cd "$ROOT"
 # (libstdc++ beside the runtime: its __cxa_throw interceptor needs the real one resolvable when python loads the library)
 NIMBLE_LIB_DIR=$OUT/lib LD_PRELOAD="$RT /usr/lib/x86_64-linux-gnu/libstdc++.so.6" \
-  python -m pytest tests -q -s -m "not gpu" > $OUT/out.txt 2>&1
+  python -m pytest ${SAN_TESTS:-tests} -q -s -m "not gpu" > $OUT/out.txt 2>&1
 echo "pytest rc=$?"
 grep -a "runtime error\|ERROR: AddressSanitizer\|WARNING: ThreadSanitizer\|passed\|failed" $OUT/out.txt | sort | uniq -c
