@@ -42,12 +42,6 @@ namespace nimble {
 namespace parse {
 namespace bam {
 
-const char *const BAM_FIELDS_TO_REPORT[38] = {
-    "QNAME", "QUAL", "REVERSE", "MATE_REVERSE", "PAIRED", "PROPER_PAIRED", "PAIR_ORIENTATION", "UNMAPPED",
-    "MATE_UNMAPPED", "FIRST_IN_TEMPLATE", "LAST_IN_TEMPLATE", "STRAND", "MAPQ", "POS", "MATE_POS", "SEQ", "SEQ_LEN",
-    "INSERT_SIZE", "QUALITY_FAILED", "SECONDARY", "DUPLICATE", "SUPPLEMENTARY", "NH", "HI", "AS", "GN", "TX", "AN", "nM",
-    "fx", "RE", "CR", "CY", "CB", "UR", "UY", "UB", "SKIP_ALIGN"};
-
 // what a record's Raw says about its body (lengths, aux offset, the CB / UB / UR string tags); false = the lengths do not fit
 // the body ("truncated record").  Defined below the reader.
 static bool describe_record(const uint8_t *body, uint32_t block, Raw &r);
@@ -1272,7 +1266,8 @@ void process(const std::vector<std::string> &input_files,
 
   double t_prep = 0, t_call = 0, t_rows = 0, t_write = 0, t_free = 0;
   PinBuf b_mem[2], q_mem[2];
-  const unsigned row_threads = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
+  unsigned row_threads = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
+  if (const char *e = getenv("NIMBLE_BAM_ROW_THREADS")) row_threads = (unsigned)std::max(1, atoi(e));
   auto flush = [&]() {
     if (store.groups.empty()) return;
     const size_t n_groups = store.groups.size();
@@ -1495,14 +1490,16 @@ void process(const std::vector<std::string> &input_files,
   std::condition_variable qcv;
   std::deque<std::unique_ptr<Batch>> queue;
   bool quit = false;
-  double t_read = 0;
+  double t_read = 0, t_read_blocked = 0;
   std::thread reader_thread([&] {
     std::unique_ptr<Batch> cur(new Batch());
     size_t cur_pairs = 0;
     auto push = [&](bool last) {
       cur->last = last;
+      const auto tb = std::chrono::steady_clock::now();
       std::unique_lock<std::mutex> lk(qmu);
       qcv.wait(lk, [&] { return quit || queue.size() < 2; });
+      t_read_blocked += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
       if (quit) return false;
       queue.push_back(std::move(cur));
       lk.unlock();
@@ -1569,10 +1566,10 @@ void process(const std::vector<std::string> &input_files,
   reader_thread.join();
   if (!failure.empty()) throw Panic(failure);
   if (getenv("NIMBLE_HOST_TIMING"))
-    fprintf(stderr, "[nimble host] bam pipeline: reader thread %.2f s (BGZF, records, UMI groups); consumer %.2f s waiting for it, "
+    fprintf(stderr, "[nimble host] bam pipeline: reader thread %.2f s (BGZF, records, UMI groups; %.2f of it waiting for the consumer); consumer %.2f s waiting for it, "
             "%.2f s in calls and rows (%.2f preparing the calls' inputs, %.2f in the calls, %.2f making and writing rows, of which "
-            "%.2f handing them to the gzip writer; %.2f freeing the batch)\n", t_read, t_wait, t_flush, t_prep, t_call, t_rows, t_write,
-            t_free);
+            "%.2f handing them to the gzip writer; %.2f freeing the batch)\n", t_read, t_read_blocked, t_wait, t_flush, t_prep, t_call,
+            t_rows, t_write, t_free);
   for (size_t i = 0; i < n_lib; ++i) {
     if (out[i]->close()) printf("Successfully flushed and closed file %zu\n", i);
     else fprintf(stderr, "Error finishing GZIP for file %zu\n", i);
