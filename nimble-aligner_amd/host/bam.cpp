@@ -42,6 +42,12 @@ namespace nimble {
 namespace parse {
 namespace bam {
 
+const char *const BAM_FIELDS_TO_REPORT[38] = {
+    "QNAME", "QUAL", "REVERSE", "MATE_REVERSE", "PAIRED", "PROPER_PAIRED", "PAIR_ORIENTATION", "UNMAPPED",
+    "MATE_UNMAPPED", "FIRST_IN_TEMPLATE", "LAST_IN_TEMPLATE", "STRAND", "MAPQ", "POS", "MATE_POS", "SEQ", "SEQ_LEN",
+    "INSERT_SIZE", "QUALITY_FAILED", "SECONDARY", "DUPLICATE", "SUPPLEMENTARY", "NH", "HI", "AS", "GN", "TX", "AN", "nM",
+    "fx", "RE", "CR", "CY", "CB", "UR", "UY", "UB", "SKIP_ALIGN"};
+
 // what a record's Raw says about its body (lengths, aux offset, the CB / UB / UR string tags); false = the lengths do not fit
 // the body ("truncated record").  Defined below the reader.
 static bool describe_record(const uint8_t *body, uint32_t block, Raw &r);
