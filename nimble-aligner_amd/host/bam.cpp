@@ -77,9 +77,10 @@ struct Reader::Impl {
   std::thread producer;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::unique_ptr<Chunk>> queue;
+  std::deque<std::shared_ptr<Chunk>> queue;
   bool quit = false;
-  std::unique_ptr<Chunk> cur;
+  std::shared_ptr<Chunk> cur;
+  Hold hold;  // what the record returned last lies in: `cur`, or a buffer of its own for a record that straddled two batches
   size_t cur_at = 0;
   bool ended = false;
   double waited = 0;  // the record decoder waiting for inflated data
@@ -137,7 +138,7 @@ struct Reader::Impl {
     int prescan = 0;  // 0 = header not seen yet, 1 = on, -1 = off
     std::vector<uint8_t> tail;
     for (;;) {
-      std::unique_ptr<Chunk> ch(new Chunk());
+      std::shared_ptr<Chunk> ch(new Chunk());
       // fill the compressed window
       if (comp.size() < have + BATCH_IN) comp.resize(have + BATCH_IN);
       while (!file_end && have < BATCH_IN) {
@@ -437,15 +438,17 @@ inline size_t b_seq_at(const uint8_t *b) { return 32 + (size_t)b_lname(b) + 4ull
 const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
 }  // namespace
 
-bool Reader::next_raw(std::vector<uint8_t> &arena, Raw &r) {
+const Hold &Reader::hold() const { return impl_->hold; }
+
+bool Reader::next_raw(Raw &r) {
   bool eof = false;
   int32_t block = 0;
   if (!impl_->f && impl_->more_data()) {
     const uint8_t *body = nullptr;
     if (const Impl::Pre *p = impl_->described(body)) {
       r = p->raw;
-      r.off = (uint32_t)arena.size();
-      arena.insert(arena.end(), body, body + r.len);
+      r.body = body;
+      if (impl_->hold.get() != impl_->cur.get()) impl_->hold = impl_->cur;
       return true;
     }
   }
@@ -454,23 +457,25 @@ bool Reader::next_raw(std::vector<uint8_t> &arena, Raw &r) {
     throw Panic("0: Found truncated record");  // parse/bam.rs:136-139
   }
   if (block < 32) throw Panic("0: Found truncated record");
-  const size_t at = arena.size();
-  if (const uint8_t *src = impl_->contiguous((size_t)block)) {
-    arena.insert(arena.end(), src, src + block);  // (the usual case: the body lies inside one inflated batch)
-  } else {
-    arena.resize(at + (size_t)block);
-    if (!impl_->read_exact(arena.data() + at, (size_t)block, eof)) throw Panic("0: Found truncated record");
+  if (const uint8_t *src = impl_->contiguous((size_t)block)) {  // inside one inflated batch, only not described
+    if (!describe_record(src, (uint32_t)block, r)) throw Panic("0: Found truncated record");
+    r.body = src;
+    if (impl_->hold.get() != impl_->cur.get()) impl_->hold = impl_->cur;
+    return true;
   }
-  if (!describe_record(arena.data() + at, (uint32_t)block, r)) throw Panic("0: Found truncated record");
-  r.off = (uint32_t)at;
+  // a record that straddles two batches (or a file that is no BGZF): its bytes are put together in a buffer of their own
+  std::shared_ptr<std::vector<uint8_t>> own(new std::vector<uint8_t>((size_t)block));
+  if (!impl_->read_exact(own->data(), (size_t)block, eof)) throw Panic("0: Found truncated record");
+  if (!describe_record(own->data(), (uint32_t)block, r)) throw Panic("0: Found truncated record");
+  r.body = own->data();
+  impl_->hold = own;
   return true;
 }
 
 bool Reader::next(Record &r) {
-  impl_->buf.clear();
   Raw raw;
-  if (!next_raw(impl_->buf, raw)) return false;
-  const uint8_t *p = impl_->buf.data();
+  if (!next_raw(raw)) return false;
+  const uint8_t *p = raw.body;
   r.tid = ld_i32(p);
   r.pos = ld_i32(p + 4);
   const uint32_t l_read_name = b_lname(p);
@@ -756,47 +761,38 @@ SortedBamReader::SortedBamReader(const std::string &path, bool force_bam_paired)
 
 void SortedBamReader::fill_buffer() {
   buffer_.clear();
-  arena_.clear();
-  for (Raw r : next_records_) {  // (the first record of this UMI, read when the UMI before ended)
-    const uint32_t at = (uint32_t)arena_.size();
-    arena_.insert(arena_.end(), next_arena_.begin() + r.off, next_arena_.begin() + r.off + r.len);
-    r.off = at;
-    buffer_.push_back(r);
-  }
+  holds_.clear();
+  ++generation_;
+  for (const Raw &r : next_records_) buffer_.push_back(r);  // (the first record of this UMI, read when the UMI before ended)
+  if (!next_records_.empty()) holds_.push_back(next_hold_);
   next_records_.clear();
-  next_arena_.clear();
+  next_hold_.reset();
   current_umi_ = next_umi_;
   Raw rec;
   for (;;) {
-    const size_t mark = arena_.size();
-    if (!reader_.next_raw(arena_, rec)) break;
-    const uint8_t *b = arena_.data() + rec.off;
+    if (!reader_.next_raw(rec)) break;
+    const uint8_t *b = rec.body;
     bool keep = !(!(rec.flag & 0x1) && force_bam_paired_);
     if (keep) keep = rec.cb_len != Raw::NONE;  // no cell barcode: not reported
     if (keep) {
       if (rec.umi_len == Raw::NONE) throw Panic("Error -- Could not read UMI.");
       keep = !(rec.umi_len == 10 && memcmp(b + rec.umi, "AAAAAAAAAA", 10) == 0);
     }
-    if (!keep) {
-      arena_.resize(mark);
-      continue;
-    }
+    if (!keep) continue;
     const char *um = reinterpret_cast<const char *>(b + rec.umi);
     if (current_umi_.empty()) current_umi_.assign(um, rec.umi_len);
     if (current_umi_.size() != rec.umi_len || memcmp(current_umi_.data(), um, rec.umi_len) != 0) {
       // records of one UMI ordered by cell barcode (a stable sort, like Vec::sort_by)
-      const uint8_t *A = arena_.data();
-      std::stable_sort(buffer_.begin(), buffer_.end(), [A](const Raw &x, const Raw &y) {
-        const int c = memcmp(A + x.off + x.cb, A + y.off + y.cb, std::min(x.cb_len, y.cb_len));
+      std::stable_sort(buffer_.begin(), buffer_.end(), [](const Raw &x, const Raw &y) {
+        const int c = memcmp(x.body + x.cb, y.body + y.cb, std::min(x.cb_len, y.cb_len));
         return c < 0 || (c == 0 && x.cb_len < y.cb_len);
       });
       next_umi_.assign(um, rec.umi_len);
-      next_arena_.assign(arena_.begin() + (long)mark, arena_.end());
-      arena_.resize(mark);
-      rec.off = 0;
       next_records_.push_back(rec);
+      next_hold_ = reader_.hold();
       return;
     }
+    if (holds_.empty() || holds_.back().get() != reader_.hold().get()) holds_.push_back(reader_.hold());
     buffer_.push_back(rec);
   }
 }
@@ -807,7 +803,7 @@ void SortedBamReader::add_dummy_paired_reads() {
   for (Raw &r : buffer_) {
     r.skip = 1;
     out.push_back(r);
-    if (!(b_flag(arena_.data() + r.off) & 0x1)) {
+    if (!(r.flag & 0x1)) {
       Raw dummy = r;  // (the same bytes: the dummy differs in the pushed tag alone)
       dummy.skip = 2;
       out.push_back(dummy);
@@ -819,14 +815,13 @@ void SortedBamReader::add_dummy_paired_reads() {
 void SortedBamReader::filter_paired_reads() {
   std::vector<Raw> out;
   out.reserve(buffer_.size());
-  const uint8_t *A = arena_.data();
-  auto qn = [A](const Raw &r) {
-    const uint8_t *b = A + r.off;
+  auto qn = [](const Raw &r) {
+    const uint8_t *b = r.body;
     const uint32_t ln = b_lname(b);
     return std::string(reinterpret_cast<const char *>(b + 32), ln ? ln - 1 : 0);
   };
-  auto same_name = [A](const Raw &x, const Raw &y) {
-    const uint8_t *a = A + x.off, *b = A + y.off;
+  auto same_name = [](const Raw &x, const Raw &y) {
+    const uint8_t *a = x.body, *b = y.body;
     const uint32_t la = b_lname(a) ? b_lname(a) - 1 : 0, lb = b_lname(b) ? b_lname(b) - 1 : 0;
     return la == lb && memcmp(a + 32, b + 32, la) == 0;
   };
@@ -837,7 +832,7 @@ void SortedBamReader::filter_paired_reads() {
   while (i < buffer_.size()) {
     if (i + 1 >= buffer_.size()) break;
     if (same_name(buffer_[i], buffer_[i + 1])) {
-      if (b_flag(A + buffer_[i].off) & 0x40) {
+      if (buffer_[i].flag & 0x40) {
         out.push_back(buffer_[i]);
         out.push_back(buffer_[i + 1]);
       } else {
@@ -856,7 +851,7 @@ void SortedBamReader::filter_paired_reads() {
   buffer_.swap(out);
 }
 
-bool SortedBamReader::next(Raw &out, const uint8_t *&arena) {
+bool SortedBamReader::next(Raw &out) {
   if (cursor_ >= buffer_.size()) {
     fill_buffer();
     if (!force_bam_paired_) add_dummy_paired_reads();
@@ -865,7 +860,6 @@ bool SortedBamReader::next(Raw &out, const uint8_t *&arena) {
     if (buffer_.empty()) return false;  // (the reference reports BamTruncatedRecord here: its end-of-input signal)
   }
   out = buffer_[cursor_++];
-  arena = arena_.data();
   return true;
 }
 
@@ -876,12 +870,12 @@ UMIReader::UMIReader(const std::string &path, bool terminate_on_error, bool forc
 std::string UmiBatch::umi_of(size_t g) const {
   if (groups[g].count == 0) return std::string();
   const Raw &r = recs[groups[g].first];
-  return std::string(reinterpret_cast<const char *>(arena.data() + r.off + r.umi), r.umi_len);
+  return std::string(reinterpret_cast<const char *>(r.body + r.umi), r.umi_len);
 }
 std::string UmiBatch::cell_of(size_t g) const {
   if (groups[g].count == 0) return std::string();
   const Raw &r = recs[groups[g].first + groups[g].count - 1];
-  return std::string(reinterpret_cast<const char *>(arena.data() + r.off + r.cb), r.cb_len >= 2 ? r.cb_len - 2 : 0);
+  return std::string(reinterpret_cast<const char *>(r.body + r.cb), r.cb_len >= 2 ? r.cb_len - 2 : 0);
 }
 
 // A group starts with the record that ended the group before it (kept aside) and grows until a record of another (UMI, cell
@@ -889,27 +883,34 @@ std::string UmiBatch::cell_of(size_t g) const {
 bool UMIReader::next_group(UmiBatch &st) {
   UmiBatch::Group g;
   g.first = (uint32_t)st.recs.size();
-  auto take = [&](const uint8_t *b, Raw rec) {
-    rec.off = (uint32_t)st.arena.size();
-    st.arena.insert(st.arena.end(), b, b + rec.len);
+  // the batch keeps what its records lie in: the holds of the sorted reader's current UMI, added once per UMI and batch
+  auto keep_holds = [&](const std::vector<Hold> &hs) {
+    for (const Hold &h : hs) {
+      bool have = false;
+      for (size_t k = st.holds.size(); k-- > 0 && k + 4 > st.holds.size();) have |= st.holds[k].get() == h.get();
+      if (!have) st.holds.push_back(h);
+    }
+  };
+  if (st.holds.empty()) merged_generation_ = ~0ULL;  // (a batch just begun)
+  auto take = [&](const Raw &rec) {
     st.recs.push_back(rec);
     ++g.count;
   };
   if (have_pend_) {
-    take(pend_bytes_.data(), pend_);
+    keep_holds(pend_holds_);
+    take(pend_);
     have_pend_ = false;
   }
   current_iteration_key_ = next_iteration_key_;
   next_iteration_key_.clear();
   Raw rec;
-  const uint8_t *A = nullptr;
   std::string key;
   bool more = false;
   for (;;) {
-    if (!reader_.next(rec, A)) break;
+    if (!reader_.next(rec)) break;
     ++read_counter_;
     if (read_counter_ % 1000000 == 0) printf("Aligned reads %zu-%zu\n", read_counter_ - 1000000, read_counter_);
-    const uint8_t *b = A + rec.off;
+    const uint8_t *b = rec.body;
     // (SortedBamReader hands on only records with a UMI and a cell barcode: the reference's checks here cannot fail)
     const char *um = reinterpret_cast<const char *>(b + rec.umi);
     const char *cb = reinterpret_cast<const char *>(b + rec.cb);
@@ -929,10 +930,14 @@ bool UMIReader::next_group(UmiBatch &st) {
     // (whether the quality bytes are text -- Phred bytes are 0..93, 0xFF = absent is no ASCII -- is looked at where the
     // qualities are copied: raw_call_input for the pipeline, UMIReader::next for the string form)
     if (same) {
-      take(b, rec);
+      if (merged_generation_ != reader_.generation()) {
+        keep_holds(reader_.holds());
+        merged_generation_ = reader_.generation();
+      }
+      take(rec);
     } else {
-      pend_bytes_.assign(b, b + rec.len);
       pend_ = rec;
+      pend_holds_ = reader_.holds();
       have_pend_ = true;
       make_key();
       next_iteration_key_ = key;
@@ -952,13 +957,13 @@ bool UMIReader::next() {  // true = that was the final UMI
   current_umi_group.assign(st.recs.size(), std::string());
   current_metadata_group.assign(st.recs.size(), std::vector<std::string>());
   for (size_t i = 0; i < st.recs.size(); ++i) {
-    if (raw_quality_is_text(st.arena.data() + st.recs[i].off, st.recs[i])) {
+    if (raw_quality_is_text(st.recs[i].body, st.recs[i])) {
       st.recs[i].qual_bad = 0;
     } else {
       puts("QUAL parsing warning: invalid utf-8 sequence");
       st.recs[i].qual_bad = 1;
     }
-    raw_fields(st.arena.data() + st.recs[i].off, st.recs[i], current_metadata_group[i]);
+    raw_fields(st.recs[i].body, st.recs[i], current_metadata_group[i]);
     current_umi_group[i] = current_metadata_group[i][15];
   }
   return !more;
@@ -1277,7 +1282,6 @@ void process(const std::vector<std::string> &input_files,
   auto flush = [&]() {
     if (store.groups.empty()) return;
     const size_t n_groups = store.groups.size();
-    const uint8_t *const arena = store.arena.data();
     const auto tp0 = std::chrono::steady_clock::now();
     // the call's inputs: R1 = record 2k, R2 = record 2k + 1, each reverse-complemented when the BAM says the read was
     // (process/bam.rs:245-303); the quality strings are already in read direction (parse/bam.rs:270-287).  Lengths first
@@ -1316,16 +1320,16 @@ void process(const std::vector<std::string> &input_files,
         for (size_t i = c * CH; i < std::min<size_t>(n, (c + 1) * CH); ++i) {
           for (int m = 0; m < 2; ++m) {
             const parse::bam::Raw &R = store.recs[where[i] + (size_t)m];
-            if (!parse::bam::raw_quality_is_text(arena + R.off, R)) {
+            if (!parse::bam::raw_quality_is_text(R.body, R)) {
               // (the reference warns and reads the field as empty; a call cannot trim a read without its qualities)
               puts("QUAL parsing warning: invalid utf-8 sequence");
               if (off[m][i + 1] != off[m][i]) {
                 std::vector<std::string> md;
-                parse::bam::raw_fields(arena + R.off, R, md);
+                parse::bam::raw_fields(R.body, R, md);
                 throw Panic("BAM record without usable qualities (" + md[0] + "): not supported by the MI355X build");
               }
             }
-            parse::bam::raw_call_input(arena + R.off, R, b[m] + off[m][i], q[m] + off[m][i]);
+            parse::bam::raw_call_input(R.body, R, b[m] + off[m][i], q[m] + off[m][i]);
             skip[m][i] = R.skip == 2 ? 1 : 0;
           }
         }
@@ -1420,7 +1424,7 @@ void process(const std::vector<std::string> &input_files,
             for (size_t k = 0; k < np; ++k) last[k] = last_of_key.at(key_of(k));
           }
           auto qname_of = [&](size_t rec) {
-            const uint8_t *body = arena + recs[rec].off;
+            const uint8_t *body = recs[rec].body;
             const uint32_t ln = body[8];
             return std::make_pair(reinterpret_cast<const char *>(body + 32), ln ? ln - 1 : 0u);
           };
@@ -1432,9 +1436,9 @@ void process(const std::vector<std::string> &input_files,
             line += '\t';
             parse::bam::append_int(line, count);
             line += '\t';
-            parse::bam::raw_row_fields(arena + m2.off, m2, line);
+            parse::bam::raw_row_fields(m2.body, m2, line);
             line += '\t';
-            parse::bam::raw_row_fields(arena + m1.off, m1, line);
+            parse::bam::raw_row_fields(m1.body, m1, line);
             line += '\t';
             line += align::to_string(fr.r2);  // "r1": the mate
             line += '\t';
@@ -1529,8 +1533,7 @@ void process(const std::vector<std::string> &input_files,
           break;
         }
         cur_pairs += cur->store.groups.back().count / 2;
-        // (record offsets are 32-bit: a batch is closed well before its arena reaches that)
-        if ((cur_pairs >= batch_pairs || cur->store.arena.size() > (1ull << 31)) && !push(false)) return;
+        if (cur_pairs >= batch_pairs && !push(false)) return;
         has_aligned = true;
       }
       t_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

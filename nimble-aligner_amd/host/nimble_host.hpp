@@ -473,11 +473,14 @@ struct Record {
   bool aux_string(const char *tag, std::string &out) const;  // Aux::String (type Z) only
 };
 extern const char *const BAM_FIELDS_TO_REPORT[38];  // src/parse/bam.rs:9-49
-// A record by reference (the pipeline's own form): the body bytes -- everything behind block_size -- sit in an arena, and
-// what the grouping needs of the aux data was found in ONE walk over it when the record came in.  Every reported field is
-// formatted straight from these bytes when a row is written; no string is built per field and record.
+// A record by reference (the pipeline's own form): the body bytes -- everything behind block_size -- stay where the BGZF
+// reader inflated them (kept alive by a Hold, below), and what the grouping needs of the aux data was found in ONE walk over it
+// when the record came in.  Every reported field is formatted straight from these bytes when a row is written; no string is
+// built per field and record, and the bytes are not copied on their way through the readers (two copies per record that
+// missed the cache were most of the decoder thread's 250 ns).
 struct Raw {
-  uint32_t off = 0, len = 0;         // the body inside the arena
+  const uint8_t *body = nullptr;     // the body (valid while the Hold that came with the record is)
+  uint32_t len = 0;
   uint32_t aux = 0;                  // where the aux data starts inside the body
   uint32_t cb = 0, cb_len = 0;       // value of CB:Z inside the body; cb_len = NONE: no such string tag
   uint32_t umi = 0, umi_len = 0;     // value of UB:Z, else of UR:Z
@@ -487,13 +490,16 @@ struct Raw {
   uint8_t qual_bad = 0;              // the quality bytes are no ASCII (0xFF = absent): reported once, the field reads empty
   static constexpr uint32_t NONE = 0xFFFFFFFFu;
 };
+using Hold = std::shared_ptr<const void>;  // keeps a piece of inflated BAM data alive
 class Reader {
  public:
   explicit Reader(const std::string &path);
   ~Reader();
   bool next(Record &r);  // false at end of file; panics on a truncated record
-  // the same record appended to `arena` (body bytes only), aux offset set, tags not looked at yet
-  bool next_raw(std::vector<uint8_t> &arena, Raw &r);
+  // the same record by reference, described (lengths, aux offset, CB / UMI tags); r.body stays valid while hold() -- as it
+  // reads right after the call -- is kept
+  bool next_raw(Raw &r);
+  const Hold &hold() const;
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
@@ -502,7 +508,9 @@ class Reader {
 class SortedBamReader {
  public:
   SortedBamReader(const std::string &path, bool force_bam_paired);
-  bool next(Raw &out, const uint8_t *&arena);  // `arena` stays valid until the call that returns the first record of the next UMI
+  bool next(Raw &out);  // out.body stays valid while the holds() of that moment are kept
+  const std::vector<Hold> &holds() const { return holds_; }
+  uint64_t generation() const { return generation_; }  // changes whenever holds() does
  private:
   void fill_buffer();
   void add_dummy_paired_reads();
@@ -510,22 +518,24 @@ class SortedBamReader {
   Reader reader_;
   bool force_bam_paired_;
   std::string current_umi_, next_umi_;
-  std::vector<uint8_t> arena_, next_arena_;
+  std::vector<Hold> holds_;   // what the records of buffer_ and next_records_ lie in
+  Hold next_hold_;
+  uint64_t generation_ = 0;
   std::vector<Raw> buffer_, next_records_;
   size_t cursor_ = 0;
 };
-// (UMI, cell barcode) groups of src/parse/bam.rs:51-288 by reference, many of them in ONE arena and ONE record array (a group
-// of its own vectors cost two allocations made by the reader thread and freed by the consumer: half a million groups of a
-// 4 M-pair file took the consumer a second to free).  Records 2k / 2k + 1 of a group are a pair.
+// (UMI, cell barcode) groups of src/parse/bam.rs:51-288 by reference, many of them in ONE record array (a group of its own
+// vectors cost two allocations made by the reader thread and freed by the consumer: half a million groups of a 4 M-pair file
+// took the consumer a second to free).  Records 2k / 2k + 1 of a group are a pair.
 struct UmiBatch {
-  std::vector<uint8_t> arena;
+  std::vector<Hold> holds;  // the inflated data the records' bodies lie in
   std::vector<Raw> recs;
   struct Group {
     uint32_t first = 0, count = 0;  // in recs
   };
   std::vector<Group> groups;
   void clear() {
-    arena.clear();
+    holds.clear();
     recs.clear();
     groups.clear();
   }
@@ -561,9 +571,10 @@ class UMIReader {
   [[maybe_unused]] bool terminate_on_error_;  // the reference panics on every record error it meets, whatever this says
   size_t read_counter_ = 0;
   // the record that ended the group before: the first of the next group
-  std::vector<uint8_t> pend_bytes_;
   Raw pend_;
+  std::vector<Hold> pend_holds_;
   bool have_pend_ = false;
+  uint64_t merged_generation_ = ~0ULL;  // SortedBamReader::generation() whose holds the batch in hand has already
   std::string current_iteration_key_, next_iteration_key_;
 };
 }  // namespace bam
