@@ -1277,7 +1277,7 @@ void process(const std::vector<std::string> &input_files,
 
   double t_prep = 0, t_call = 0, t_rows = 0, t_write = 0, t_free = 0;
   PinBuf b_mem[2], q_mem[2];
-  unsigned row_threads = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
+  unsigned row_threads = std::max(1u, std::min(parse::usable_cpus() * 3 / 4, 12u));
   if (const char *e = getenv("NIMBLE_BAM_ROW_THREADS")) row_threads = (unsigned)std::max(1, atoi(e));
   auto flush = [&]() {
     if (store.groups.empty()) return;
