@@ -1955,6 +1955,11 @@ int nimble_read_records(nimble_ctx *c, int mate, int32_t *reason, int32_t *score
 // development aid, not part of the ABI in include/nimble_hip.h: section clocks of k_align in a profiling build
 extern "C" int nimble_debug_sections(uint64_t out[16], int reset) { return debug_sections(out, reset); }
 // the 16 state words of the context's last finished call (kernels.h CallBuffers::state)
+// (test hook, not part of the interface) leave a stale error in THIS process's HIP runtime -- the one this library is linked
+// against -- the way a foreign library's failed call would: returns the hipError_t of hipSetDevice(999).  (A test that
+// loads "libamdhip64.so" by name may get a second copy of the runtime beside torch's: two runtimes in one process.)
+extern "C" int nimble_debug_stale_error(void) { return (int)hipSetDevice(999); }
+
 extern "C" int nimble_debug_state(nimble_ctx *c, uint64_t out[16]) {
   if (!c || !out || !c->called) return NIMBLE_E_INVALID;
   int rc = finish_count_stage(c);

@@ -282,7 +282,7 @@ def test_index_freed_before_its_context():
 
 def test_a_stale_hip_error_of_another_library_does_not_fail_a_healthy_call():
     """HIP keeps the last error of any earlier call in the process until somebody reads it.  Provoke one behind the
-    library's back (hipSetDevice(999) straight through the HIP runtime), then make an ordinary call: it must succeed
+    library's back (a failed hipSetDevice(999) in the same HIP runtime), then make an ordinary call: it must succeed
     (round 2: the check behind a kernel launch reported whatever error an earlier, unrelated call had left)."""
     import ctypes as C
     names, seqs = synth.make_library(12)
@@ -290,15 +290,10 @@ def test_a_stale_hip_error_of_another_library_does_not_fail_a_healthy_call():
     import json
     lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index(0)
     want = [(f, c) for f, c in lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)]
-    hip = None
-    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
-        try:
-            hip = C.CDLL(name)
-            break
-        except OSError:
-            continue
-    assert hip is not None, "HIP runtime not loadable"
-    assert hip.hipSetDevice(C.c_int(999)) != 0          # leaves hipErrorInvalidDevice as the process's last error
+    # (through the library's own link to the HIP runtime: loading "libamdhip64.so" by name here can bring a SECOND copy of
+    # the runtime into the process beside the one torch ships -- the round-3 suite once aborted in the test after this one)
+    hip = nim.hip_lib()
+    hip.nimble_debug_stale_error.restype = C.c_int
+    assert hip.nimble_debug_stale_error() != 0          # leaves hipErrorInvalidDevice as the process's last error
     got = [(f, c) for f, c in lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)]
     assert got == want
-    hip.hipSetDevice(C.c_int(0))

@@ -22,15 +22,11 @@ for f in reference_library align fastq pgzip bam multi host_capi; do
   g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off $FLAGS -fno-omit-frame-pointer -c host/$f.cpp -o $OUT/obj/$f.o 2>&1 | grep -E "error:" && exit 1
   OBJS="$OBJS $OUT/obj/$f.o"
 done
-if [ $KIND = asan ]; then
-  # the index builder (csrc/flat_index.cpp, plain C++ inside the device library) instrumented too; the HIP objects as built
-  g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off $FLAGS -fno-sanitize=vptr -fno-omit-frame-pointer -pthread -c csrc/flat_index.cpp -o $OUT/obj/flat_index.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/lib/libnimble_hip.so build/kernels.o build/capi.o $OUT/obj/flat_index.o \
-    -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-z,undefs || exit 1
-  RT="$RT $(gcc -print-file-name=libubsan.so)"
-else
-  cp lib/libnimble_hip.so $OUT/lib/
-fi
+# the index builder (csrc/flat_index.cpp, plain C++ inside the device library) instrumented too; the HIP objects as built
+g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off $FLAGS -fno-sanitize=vptr -fno-omit-frame-pointer -pthread -c csrc/flat_index.cpp -o $OUT/obj/flat_index.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/lib/libnimble_hip.so build/kernels.o build/capi.o $OUT/obj/flat_index.o \
+  -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,-z,undefs || exit 1
+[ $KIND = asan ] && RT="$RT $(gcc -print-file-name=libubsan.so)"
 g++ -shared $FLAGS -o $OUT/lib/libnimble_host.so $OBJS -L$OUT/lib -lnimble_hip -lz -pthread -Wl,-rpath,'$ORIGIN' || exit 1
 cd "$ROOT"
 # (libstdc++ beside the runtime: its __cxa_throw interceptor needs the real one resolvable when python loads the library)
