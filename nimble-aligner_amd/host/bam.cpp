@@ -183,7 +183,12 @@ struct Reader::Impl {
       }
       ch->data.resize(out_total);
       std::atomic<size_t> next{0};
-      std::atomic<bool> bad{false};
+      std::atomic<size_t> first_bad{~(size_t)0};  // the first member that does not inflate to its size and CRC
+      auto mark_bad = [&](size_t i) {
+        size_t cur_min = first_bad.load();
+        while (i < cur_min && !first_bad.compare_exchange_weak(cur_min, i)) {
+        }
+      };
       auto work = [&] {
         z_stream z;
         for (;;) {
@@ -192,7 +197,7 @@ struct Reader::Impl {
           const Member &m = ms[i];
           memset(&z, 0, sizeof z);
           if (inflateInit2(&z, -15) != Z_OK) {
-            bad = true;
+            mark_bad(i);
             return;
           }
           z.next_in = comp.data() + m.at + m.data_at;
@@ -203,7 +208,7 @@ struct Reader::Impl {
           const bool ok = rc == Z_STREAM_END && z.avail_out == 0 &&
                           (uint32_t)crc32(0, ch->data.data() + m.out_at, m.isize) == m.crc;
           inflateEnd(&z);
-          if (!ok) bad = true;
+          if (!ok) mark_bad(i);
         }
       };
       if (ms.size() > 4 && helpers > 1) {
@@ -214,12 +219,15 @@ struct Reader::Impl {
       } else {
         work();
       }
+      const bool bad = first_bad.load() != ~(size_t)0;
       if (bad) {
-        ch->data.clear();
+        // what lies in front of the damaged member is good data: the decoder gets it and meets the error behind it (a reader
+        // that stops earlier -- the reference's end-of-input quirks -- never sees it, as with one zlib stream)
+        ch->data.resize(ms[first_bad.load()].out_at);
         ch->error = "Error -- could not read BAM file (corrupt BGZF block)";
         ch->truncated = false;
       }
-      if (prescan >= 0 && !bad) {
+      if (prescan >= 0) {
         const uint8_t *d = ch->data.data();
         const size_t n = ch->data.size();
         size_t pos = 0;

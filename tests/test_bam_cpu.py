@@ -107,6 +107,47 @@ def test_empty_and_truncated_files(tmp_path):
         nim.bam_umi_groups(os.path.join(os.path.dirname(__file__), "golden", "reads", "basic.fastq"))
 
 
+def test_plain_gzip_and_corrupt_blocks(tmp_path, monkeypatch):
+    """A BAM stream inside ordinary gzip (no BGZF extra field) goes through zlib's gz layer and yields the same groups; a
+    BGZF member whose payload was damaged is reported (CRC-32 / inflate), at the point where the decoder gets there."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(9)
+    recs = make_records(rng, n_umis=30)
+    bg = str(tmp_path / "b.bam")
+    bam_util.write_bam(bg, recs, block=5000)
+    want = nim.bam_umi_groups(bg, False)
+    # the same stream as one ordinary gzip member
+    raw = b""
+    data = open(bg, "rb").read()
+    d = zlib.decompressobj(31)
+    while data:
+        raw += d.decompress(data)
+        data = d.unused_data
+        if d.eof and data:
+            d = zlib.decompressobj(31)
+        elif d.eof:
+            break
+    plain = str(tmp_path / "p.bam")
+    with gzip.open(plain, "wb") as f:
+        f.write(raw)
+    assert nim.bam_umi_groups(plain, False) == want
+    # damage the deflate payload of the SECOND member (a reader that stops early -- the reference's end-of-input quirks --
+    # never reads far into the file; what lies in front of the damage is delivered, the error stands behind it)
+    data = bytearray(open(bg, "rb").read())
+    starts = [i for i in range(len(data) - 16) if data[i:i + 4] == b"\x1f\x8b\x08\x04" and data[i + 12:i + 14] == b"BC"]
+    assert len(starts) > 4
+    at = starts[1] + 30
+    data[at] ^= 0x55
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(data))
+    for batch in ("", "4096"):
+        if batch:
+            monkeypatch.setenv("NIMBLE_BGZF_BATCH", batch)
+        with pytest.raises(nim.Panic, match="corrupt BGZF block|truncated"):
+            nim.bam_umi_groups(bad, False)
+
+
 def test_reference_unit_literals():
     # src/process/bam.rs:437-471
     assert nim.reverse_comp_if_needed("ATGC", True) == "GCAT"
