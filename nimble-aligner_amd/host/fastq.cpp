@@ -1007,6 +1007,28 @@ uint64_t file_size(const std::string &p) {
   return s > 0 ? (uint64_t)s : 0;
 }
 
+// Length of the first record's sequence line and the bytes that record takes in the (inflated) file: what the call can be
+// opened with before the first parsed batch is there.  zlib's gz layer reads plain files as they are.  false = nothing usable.
+bool peek_first_record(const std::string &path, uint32_t &seq_len, uint32_t &record_bytes, bool &gz) {
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) return false;
+  char buf[1 << 16];
+  const int n = gzread(f, buf, sizeof buf);
+  gz = gzdirect(f) == 0;
+  gzclose(f);
+  if (n <= 0) return false;
+  int nl[4], k = 0;
+  for (int i = 0; i < n && k < 4; ++i)
+    if (buf[i] == '\n') nl[k++] = i;
+  if (k < 4 || buf[0] != '@') return false;
+  int len = nl[1] - nl[0] - 1;
+  if (len > 0 && buf[nl[1] - 1] == '\r') --len;
+  if (len <= 0) return false;
+  seq_len = (uint32_t)len;
+  record_bytes = (uint32_t)(nl[3] + 1);
+  return true;
+}
+
 // One input file as a stream of records: the current batch and how much of it has been consumed.
 struct Cursor {
   parse::fastq::BatchReader rd;
@@ -1051,6 +1073,22 @@ void streamed(const std::vector<std::string> &input_files,
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
+  // The call is opened (the context's arrays allocated for the whole file: ~13 ms) while the readers parse their first
+  // batches, from a look at the first record of each file: reads of that length, as many as the file's size suggests.  A
+  // first batch that holds longer reads takes the whole-file path as before; a capacity that proves too small grows.
+  if (!getenv("NIMBLE_FASTQ_LATE_OPEN")) {
+    uint32_t l1 = 0, rb1 = 0, l2 = 0, rb2 = 0;
+    bool gz1 = false, gz2 = false;
+    if (peek_first_record(input_files[0], l1, rb1, gz1) && (!paired || peek_first_record(input_files[1], l2, rb2, gz2))) {
+      const auto to = now();
+      stream_max_len = std::max<uint32_t>(32, (std::max(l1, l2) + 31u) / 32u * 32u);
+      // (a .gz holds about four times its size in text)
+      const uint64_t cap = (uint64_t)((double)file_size(input_files[0]) * (gz1 ? 4.0 : 1.0) / (double)rb1 * 1.05) + 1024;
+      for (size_t i = 0; i < reference_indices.size(); ++i)
+        streams.emplace_back(new align::CallStream(*reference_indices[i], aligner_configs.at(i), paired, stream_max_len, cap));
+      t_open += secs(to, now());
+    }
+  }
   for (;;) {
     const auto tf = now();
     c1.fill();
