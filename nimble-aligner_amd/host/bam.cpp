@@ -107,10 +107,12 @@ struct Reader::Impl {
     uint32_t isize, crc;
     size_t out_at;
   };
-  // size of the member that starts at p (n bytes available), 0 = not (yet) decidable / not BGZF
+  // size of the member that starts at p (n bytes available); 0 = not decidable yet (too few bytes), NOT_A_MEMBER = these
+  // bytes are no BGZF member whatever follows
+  static constexpr size_t NOT_A_MEMBER = ~(size_t)0;
   static size_t member_size(const uint8_t *p, size_t n, size_t &data_at) {
     if (n < 12) return 0;
-    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return NOT_A_MEMBER;
     const size_t xlen = p[10] | ((size_t)p[11] << 8);
     if (n < 12 + xlen) return 0;
     size_t o = 12;
@@ -123,7 +125,7 @@ struct Reader::Impl {
       }
       o += 4 + slen;
     }
-    return 0;
+    return NOT_A_MEMBER;  // a gzip member without the BGZF size field
   }
   void produce(unsigned helpers) {
     std::vector<uint8_t> comp;
@@ -152,18 +154,16 @@ struct Reader::Impl {
       while (at < have) {
         size_t data_at = 0;
         const size_t sz = member_size(comp.data() + at, have - at, data_at);
-        if (sz == 0 || at + sz > have) {
-          if (file_end) {
-            // the file ends inside a member (or in bytes that are no member): what zlib reported as an unexpected end
-            if (sz == 0 && have - at >= 18) ch->error = "Error -- could not read BAM file (corrupt BGZF block)";
-            else ch->truncated = true;
-            at = have;
-          }
-          break;
-        }
-        if (sz < data_at + 8) {
+        if (sz == NOT_A_MEMBER || (sz != 0 && sz < data_at + 8)) {  // (what stands in front of it is delivered first)
           ch->error = "Error -- could not read BAM file (corrupt BGZF block)";
           at = have;
+          break;
+        }
+        if (sz == 0 || at + sz > have) {
+          if (file_end) {  // the file ends inside a member: what zlib reported as an unexpected end
+            ch->truncated = true;
+            at = have;
+          }
           break;
         }
         Member m;
@@ -172,6 +172,11 @@ struct Reader::Impl {
         m.data_at = data_at;
         memcpy(&m.crc, comp.data() + at + sz - 8, 4);
         memcpy(&m.isize, comp.data() + at + sz - 4, 4);
+        if (m.isize > (1u << 16)) {  // (a BGZF member holds at most 64 KiB)
+          ch->error = "Error -- could not read BAM file (corrupt BGZF block)";
+          at = have;
+          break;
+        }
         m.out_at = out_total;
         out_total += m.isize;
         ms.push_back(m);
@@ -403,7 +408,8 @@ Reader::Reader(const std::string &path) : impl_(new Impl()) {
   uint8_t head[64];
   const size_t hn = fread(head, 1, sizeof head, impl_->fp);
   size_t data_at = 0;
-  const bool bgzf = Impl::member_size(head, hn, data_at) != 0;
+  const size_t first = Impl::member_size(head, hn, data_at);
+  const bool bgzf = first != 0 && first != Impl::NOT_A_MEMBER;
   if (bgzf) {
     rewind(impl_->fp);
     unsigned helpers = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));

@@ -141,11 +141,20 @@ def test_plain_gzip_and_corrupt_blocks(tmp_path, monkeypatch):
     data[at] ^= 0x55
     bad = str(tmp_path / "bad.bam")
     open(bad, "wb").write(bytes(data))
+    # ... or bytes that are no BGZF member at all between two members, or a member that claims more than 64 KiB
+    clean = open(bg, "rb").read()
+    junk = str(tmp_path / "junk.bam")
+    open(junk, "wb").write(clean[:starts[1]] + bytes(rng.integers(0, 256, size=200, dtype=np.uint8)) + clean[starts[1]:])
+    big = bytearray(clean)
+    big[starts[2] - 4:starts[2]] = (1 << 20).to_bytes(4, "little")      # ISIZE of the second member
+    huge = str(tmp_path / "huge.bam")
+    open(huge, "wb").write(bytes(big))
     for batch in ("", "4096"):
         if batch:
             monkeypatch.setenv("NIMBLE_BGZF_BATCH", batch)
-        with pytest.raises(nim.Panic, match="corrupt BGZF block|truncated"):
-            nim.bam_umi_groups(bad, False)
+        for path in (bad, junk, huge):
+            with pytest.raises(nim.Panic, match="corrupt BGZF block|truncated"):
+                nim.bam_umi_groups(path, False)
 
 
 def test_reference_unit_literals():
