@@ -125,6 +125,31 @@ def e2e_fastq(names, seqs, reads_np, n_plain, n_gz):
     return out
 
 
+def e2e_bam(pairs):
+    """The BAM pipeline end to end through the CLI (BGZF -> records -> UMI groups -> device calls -> one gzip-compressed TSV row
+    per read pair) on a synthetic 10x-style BAM written by tools/e2e_bam.py: wall time of the whole process."""
+    exe = os.path.join(ROOT, "nimble-aligner_amd", "lib", "nimble")
+    d = tempfile.mkdtemp(prefix="nimble_bam_", dir="/tmp")
+    try:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bam.py"), "write", d, str(pairs), "8"], check=True,
+                       capture_output=True)
+        walls = []
+        for _ in range(2):  # (the first run warms the page cache)
+            t0 = time.perf_counter()
+            cp = subprocess.run([exe, "-r", d + "/lib.json", "-o", d + "/out.tsv.gz", "-i", d + "/in.bam"], capture_output=True,
+                                text=True)
+            walls.append(time.perf_counter() - t0)
+            if cp.returncode != 0:
+                raise RuntimeError(cp.stderr[-500:])
+        return {"e2e_bam_reads_per_s": 2 * pairs / walls[-1], "e2e_bam_wall_s": walls[-1],
+                "e2e_bam_note": "lib/nimble on a BAM of %d proper pairs (runs of one UMI of 8 pairs, every pair its own cell "
+                                "barcode, 10x-style tags): wall time of the process incl. start, HIP initialisation and index "
+                                "build (about 0.75 s of it); reads = 2 x pairs; the output holds a row of 36 + 36 BAM fields per "
+                                "pair" % pairs}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
 def native_leg(nim, synth, torch, lib_obj, seqs, devices, n, L, n_sets, warmup, steps):
     """The multi-GPU step through the C ABI alone (include/nimble_hip.h nimble_comm_* / nimble_steps_*, RCCL inside the
     device library; include/nimble_host.h nimble_multi_steps): ONE process, one native host thread per device, reads
@@ -190,6 +215,8 @@ def main():
                     help="also time the steps with the reads handed over as 2-bit words (0 = skip); an extra key, not `value`")
     ap.add_argument("--e2e-reads", type=int, default=16_000_000,
                     help="reads of the end-to-end FASTQ runs at N=1, plain and .gz (0 = skip)")
+    ap.add_argument("--e2e-bam-pairs", type=int, default=1_000_000,
+                    help="read pairs of the end-to-end BAM run at N=1 (0 = skip); skipped with --e2e-reads 0")
     args = ap.parse_args()
     # under a profiler the end-to-end leg is left out: it writes a FASTQ file, gzips it and starts lib/nimble children that
     # inherit the profiler's preload (their kernels would land in the counter files, and the run outlasts its timeout)
@@ -567,6 +594,11 @@ def main():
                 out.update(e2e_fastq(names, seqs, sets[0][0][:m].cpu().numpy(), m, m))
             except Exception as ex:  # the bench line must not die with the side measurement
                 out["e2e_error"] = str(ex)[:300]
+            if args.e2e_bam_pairs > 0 and args.workload == "configs2":
+                try:
+                    out.update(e2e_bam(args.e2e_bam_pairs))
+                except Exception as ex:
+                    out["e2e_bam_error"] = str(ex)[:300]
     if rank == 0 and getattr(nd, "_TIMING", None):
         k = max(nd._TIMING.get("steps", 1), 1)
         out["sharded_phase_ms"] = {a: round(b / k, 3) for a, b in nd._TIMING.items() if a != "steps"}

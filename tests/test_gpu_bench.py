@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("workload,extra", [
-    ("configs2", ["--reads", "60000", "--features", "64", "--e2e-reads", "20000", "--packed-input", "1"]),
+    ("configs2", ["--reads", "60000", "--features", "64", "--e2e-reads", "20000", "--e2e-bam-pairs", "20000", "--packed-input", "1"]),
     ("configs3", ["--reads", "30000", "--features", "64", "--e2e-reads", "0"]),
     ("families100", ["--reads", "20000", "--e2e-reads", "0"]),
     ("families500", ["--reads", "20000", "--e2e-reads", "0"]),
@@ -35,6 +35,7 @@ def test_bench_workloads_run_and_check_parity(workload, extra):
     if workload == "configs2":
         assert d["packed_input"]["reads_per_s"] > 0
         assert d["e2e_fastq_reads_per_s"] > 0 and d["e2e_fastq_gz_reads_per_s"] > 0
+        assert d["e2e_bam_reads_per_s"] > 0, d.get("e2e_bam_error")
 
 
 @pytest.mark.parametrize("extra", [["--force-sharded"], ["--native-virtual", "3"]])

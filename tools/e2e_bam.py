@@ -78,6 +78,20 @@ def write_bam(path, r1, r2, per_umi, rng):
     return len(raw)
 
 
+def write_inputs(d, pairs, per_umi):
+    """lib.json + in.bam under directory d; returns the bytes of BAM records written."""
+    names, seqs = synth.make_library(1000)
+    synth.write_library(d + "/lib.json", names, seqs)
+    r1, r2 = synth.make_reads(seqs, pairs, paired=True)
+    return write_bam(d + "/in.bam", r1, r2, per_umi, np.random.default_rng(3))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "write":
+    # python tools/e2e_bam.py write <dir> <pairs> [pairs per UMI]: the inputs only (bench.py: a fresh interpreter, the writer
+    # forks a pool and the caller holds the GPU)
+    write_inputs(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 8)
+    sys.exit(0)
+
 if __name__ == "__main__":
     pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     per_umi = int(sys.argv[2]) if len(sys.argv) > 2 else 8
