@@ -17,7 +17,8 @@ gene families of 100 alleles at 1 % divergence (the shape of the reference's own
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the dominant kernel (k_align,
 HBM-bound integer work) and `cpu_baseline` (the CPU oracle, a port, on this box's host cores), plus `step_ms` (min / median
 / max over the timed steps) and, at N=1, `e2e_fastq_reads_per_s` / `e2e_fastq_gz_reads_per_s`: the whole FASTQ pipeline
-(lib/nimble: parse, H2D, call, TSV) on a bounded file, outside the timed value.
+(lib/nimble: parse, H2D, call, TSV) on a bounded file, and `e2e_bam_reads_per_s`: the BAM pipeline on a synthetic 10x-style
+BAM, all outside the timed value.
 """
 import argparse
 import importlib
