@@ -493,6 +493,11 @@ def main():
             "stream_copy_GBps": stream_copy_gbps,
             "frac_of_stream_copy": align_bytes / align_s / 1e9 / stream_copy_gbps,
         }
+        if traffic:
+            # what the kernel really moved on the memory side of L2 (Infinity-Cache hits included), per second and against
+            # the bytes the algorithm needs: traffic well above 1 x algorithmic = lines fetched more than once
+            out["roofline"]["traffic_GBps"] = traffic / align_s / 1e9
+            out["roofline"]["traffic_over_algorithmic"] = traffic / max(align_bytes, 1)
         if out["roofline"]["frac"] > 1.0:
             # the SURVEY 8(d) formula prices what the REFERENCE algorithm reads: every colour-list entry of every visited
             # class (4 * class_entries).  With allele families of 100 a class has ~100 entries and a read visits ~120 of
