@@ -332,6 +332,11 @@ int nimble_comm_create(const int *devices, int n, nimble_comm **out);
 void nimble_comm_free(nimble_comm *);
 int nimble_comm_size(const nimble_comm *);
 int nimble_comm_uses_rccl(const nimble_comm *);
+/* A rank's driver thread that fails OUTSIDE the collectives (a host-side fault: it will never make its next collective
+ * call) calls this on its way out: the ranks waiting for it inside a collective return NIMBLE_E_INTERNAL instead of
+ * waiting forever, and so does every later collective call on this communicator.  (The reference's analogue: a worker
+ * thread that panics poisons the channel its peers wait on, src/process/bam.rs:183-226.)  Any thread may call it. */
+void nimble_comm_abort(nimble_comm *);
 /* In-place sum over the ranks of an int64 vector (counts are i32 in the reference, src/align.rs:186; int64 on the
  * wire): device memory on the rank's stream, or host memory (staged through the device, complete on return). */
 int nimble_counts_allreduce(nimble_comm *, int rank, int64_t *counts_dev, uint64_t len, void *stream);

@@ -57,6 +57,12 @@ int nimble_library_sequence_idx(const nimble_library *);
 const char *nimble_library_header(const nimble_library *, int col);
 const char *nimble_library_cell(const nimble_library *, int col, int row);
 int nimble_library_push_column(nimble_library *, const char *header, const char *const *values, int n);
+/* A `Reference` written out by hand, the way the reference's unit tests build theirs (src/align.rs:1533-1546,
+ * src/utils.rs:129-139,151-161): column c has rows_of[c] cells (columns may differ in length -- that is what
+ * utils.rs:149-164 tests), cells are given column after column; nothing is added (no reverse-complement rows), the
+ * config is a default one. */
+int nimble_library_from_table(int n_cols, const char *const *headers, const int *rows_of, const char *const *cells,
+                              int group_on, int sequence_name_idx, int sequence_idx, nimble_library **out);
 /* get_reference_sequence_data + build_index on `device`; needs a GPU */
 int nimble_library_build_index(nimble_library *, int device);
 /* the device handles behind the library's PseudoAligner (NULL before build_index); borrowed */
@@ -179,6 +185,18 @@ int nimble_write_to_tsv(const nimble_rows *, const char *output_path);
  * returns the triage FilterReason (16 = None) or -1 on panic */
 int nimble_host_coerce(const nimble_library *, int has_r1, const uint32_t *c1, int n1, int has_r2, const uint32_t *c2,
                        int n2, char *out, int cap);
+/* the pieces of the coercion the reference tests on their own (lists are '\n'-joined):
+ * AlignmentOrientation::parse_calls (src/align.rs:276-285; test :1234-1252) -> one "feature\t0|1" line per call;
+ * unmap (src/align.rs:851-864; tests :1533-1608) -> row of each feature, returns how many or -1 on its panic;
+ * process_equivalence_class_to_feature_list (src/align.rs:802-849);
+ * utils::get_reference_sequence_data (src/utils.rs:7-24; tests :127-160) -> one "name\tsequence" line per row;
+ * utils::sort_score_vector (src/utils.rs:54-59; tests :283-360) on n_rows keys ('\t'-joined strings): order[i] = input
+ * index of output row i */
+int nimble_host_parse_calls(const nimble_library *, const char *calls, char *out, int cap);
+int nimble_host_unmap(const nimble_library *, const char *features, uint32_t *out, int cap);
+int nimble_host_feature_list(const nimble_library *, const uint32_t *cls, int n, int ignore_group_rollup, char *out, int cap);
+int nimble_host_reference_sequence_data(const nimble_library *, char *out, int cap);
+int nimble_host_sort_score_vector(const char *keys, int n_rows, int32_t *order);
 int nimble_host_natural_lexical_cmp(const char *a, const char *b);
 double nimble_host_shannon_entropy(const char *dna);
 int nimble_host_revcomp(const char *seq, char *out); /* out holds strlen(seq)+1 bytes */

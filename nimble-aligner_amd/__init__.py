@@ -92,7 +92,7 @@ HIP_SYMBOLS = [
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
     "nimble_ctx_defer_dedup", "nimble_route_counts", "nimble_dedup_records", "nimble_count_verdicts",
-    "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl",
+    "nimble_call_records", "nimble_comm_create", "nimble_comm_free", "nimble_comm_size", "nimble_comm_uses_rccl", "nimble_comm_abort",
     "nimble_counts_allreduce", "nimble_counts_allreduce_host", "nimble_records_alltoall", "nimble_sharded_begin",
     "nimble_sharded_append", "nimble_sharded_append_packed", "nimble_sharded_end", "nimble_sharded_grow", "nimble_sharded_abort",
     "nimble_class_table_read", "nimble_class_pool_read", "nimble_steps_begin", "nimble_steps_submit", "nimble_steps_flush", "nimble_steps_end",
@@ -160,6 +160,8 @@ def hip_lib():
         L.nimble_comm_free.restype = None
         L.nimble_comm_size.argtypes = [vp]
         L.nimble_comm_uses_rccl.argtypes = [vp]
+        L.nimble_comm_abort.argtypes = [vp]
+        L.nimble_comm_abort.restype = None
         L.nimble_counts_allreduce.argtypes = [vp, i32, vp, u64, vp]
         L.nimble_counts_allreduce_host.argtypes = [vp, i32, vp, u64]
         L.nimble_records_alltoall.argtypes = [vp, i32, vp, vp, u32, vp, u64, C.POINTER(u64), vp]
@@ -502,10 +504,11 @@ HOST_SYMBOLS = [
     "nimble_host_last_error", "nimble_library_load", "nimble_library_parse", "nimble_library_free",
     "nimble_library_get_config", "nimble_library_set_config", "nimble_library_n_rows", "nimble_library_n_cols",
     "nimble_library_group_on", "nimble_library_set_group_on", "nimble_library_sequence_name_idx",
-    "nimble_library_sequence_idx", "nimble_library_header", "nimble_library_cell", "nimble_library_push_column",
+    "nimble_library_sequence_idx", "nimble_library_header", "nimble_library_cell", "nimble_library_push_column", "nimble_library_from_table",
     "nimble_library_build_index", "nimble_library_index", "nimble_library_ctx", "nimble_score_call",
     "nimble_score_call_fastq", "nimble_rows_free", "nimble_rows_count", "nimble_rows_get", "nimble_fastq_process",
-    "nimble_write_to_tsv", "nimble_multi_steps", "nimble_host_coerce", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
+    "nimble_write_to_tsv", "nimble_multi_steps", "nimble_host_coerce", "nimble_host_parse_calls", "nimble_host_unmap", "nimble_host_feature_list",
+    "nimble_host_reference_sequence_data", "nimble_host_sort_score_vector", "nimble_host_natural_lexical_cmp", "nimble_host_shannon_entropy",
     "nimble_host_revcomp", "nimble_host_maxinfo", "nimble_host_read_fastq", "nimble_host_filter_reason_text",
     "nimble_library_pack", "nimble_score_call_packed", "nimble_score_call_begin", "nimble_score_call_begin_words", "nimble_score_call_end",
     "nimble_library_ctx_slot", "nimble_library_pack_slot", "nimble_score_call_packed_begin",
@@ -555,6 +558,7 @@ def host_lib():
         L.nimble_library_cell.argtypes = [vp, i32, i32]
         L.nimble_library_cell.restype = cp
         L.nimble_library_push_column.argtypes = [vp, cp, pp, i32]
+        L.nimble_library_from_table.argtypes = [i32, pp, vp, pp, i32, i32, i32, C.POINTER(vp)]
         L.nimble_library_build_index.argtypes = [vp, i32]
         L.nimble_library_index.argtypes = [vp]
         L.nimble_library_index.restype = vp
@@ -612,6 +616,11 @@ def host_lib():
         L.nimble_host_pgzip_decompress.argtypes = [cp, i32, cp, C.POINTER(u64)]
         L.nimble_write_to_tsv.argtypes = [vp, cp]
         L.nimble_host_coerce.argtypes = [vp, i32, vp, i32, i32, vp, i32, cp, i32]
+        L.nimble_host_parse_calls.argtypes = [vp, cp, cp, i32]
+        L.nimble_host_unmap.argtypes = [vp, cp, vp, i32]
+        L.nimble_host_feature_list.argtypes = [vp, vp, i32, i32, cp, i32]
+        L.nimble_host_reference_sequence_data.argtypes = [vp, cp, i32]
+        L.nimble_host_sort_score_vector.argtypes = [cp, i32, vp]
         L.nimble_host_natural_lexical_cmp.argtypes = [cp, cp]
         L.nimble_host_shannon_entropy.argtypes = [cp]
         L.nimble_host_shannon_entropy.restype = C.c_double
@@ -794,6 +803,18 @@ class Library:
         else:
             _hcheck(host_lib().nimble_library_load(os.fsencode(path), sf, C.byref(h)))
         self.h = h
+
+    @classmethod
+    def from_table(cls, headers, columns, group_on, sequence_name_idx, sequence_idx):
+        """A Reference written out by hand (src/align.rs:1533-1546): nothing added, columns may differ in length."""
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        rows_of = np.asarray([len(c) for c in columns], dtype=np.int32)
+        cells = [v for col in columns for v in col]
+        _hcheck(host_lib().nimble_library_from_table(len(headers), _cstrs(headers), rows_of.ctypes.data, _cstrs(cells),
+                                                     int(group_on), int(sequence_name_idx), int(sequence_idx), C.byref(h)))
+        self.h = h
+        return self
 
     def close(self):
         if getattr(self, "h", None):
@@ -1021,6 +1042,37 @@ class Library:
                                                    os.fsencode(r2_path) if r2_path else None, C.byref(h)))
         return _rows(h)
 
+    def parse_calls(self, calls):
+        """AlignmentOrientation::parse_calls (src/align.rs:276-285) -> [(feature, is_rev)]."""
+        out = C.create_string_buffer(1 << 16)
+        _hcheck(host_lib().nimble_host_parse_calls(self.h, "\n".join(calls).encode(), out, len(out)))
+        s = out.value.decode()
+        return [(l.rsplit("\t", 1)[0], l.rsplit("\t", 1)[1] == "1") for l in s.split("\n")] if s else []
+
+    def unmap(self, features):
+        """unmap (src/align.rs:851-864)."""
+        out = np.zeros(max(1, len(features)), dtype=np.uint32)
+        n = host_lib().nimble_host_unmap(self.h, "\n".join(features).encode(), out.ctypes.data, out.size)
+        if n < 0:
+            raise Panic(host_lib().nimble_host_last_error().decode("utf-8", "replace"))
+        return [int(v) for v in out[:n]]
+
+    def feature_list(self, cls, ignore_group_rollup):
+        """process_equivalence_class_to_feature_list (src/align.rs:802-849)."""
+        a = np.ascontiguousarray(np.asarray(list(cls), dtype=np.uint32))
+        out = C.create_string_buffer(1 << 16)
+        _hcheck(host_lib().nimble_host_feature_list(self.h, a.ctypes.data, a.size, int(ignore_group_rollup), out, len(out)))
+        s = out.value.decode()
+        return s.split("\n") if s else []
+
+    def reference_sequence_data(self):
+        """utils::get_reference_sequence_data (src/utils.rs:7-24) -> (sequences, names)."""
+        out = C.create_string_buffer(1 << 22)
+        _hcheck(host_lib().nimble_host_reference_sequence_data(self.h, out, len(out)))
+        s = out.value.decode()
+        rows = [l.split("\t") for l in s.split("\n")] if s else []
+        return [r[1] for r in rows], [r[0] for r in rows]
+
     def coerce(self, c1, c2):
         """Host coercion of one (class R1, class R2) pair -> (callset, triage reason code)."""
         a1 = np.ascontiguousarray(np.asarray(list(c1 or []), dtype=np.uint32))
@@ -1032,6 +1084,22 @@ class Library:
             raise Panic(host_lib().nimble_host_last_error().decode("utf-8", "replace"))
         s = out.value.decode()
         return (s.split("\t") if s else []), r
+
+
+def dna_to_string(seq):
+    """DnaString::from_acgt_bytes(seq).to_string(): through the product's 2-bit packing (nimble_host_pack_reads_2bit) and back."""
+    words, lens, _ = pack_reads_2bit([seq])
+    n = int(lens[0])
+    w = np.asarray(words).reshape(-1)
+    return "".join("ACGT"[(int(w[i >> 5]) >> (62 - 2 * (i & 31))) & 3] for i in range(n))
+
+
+def sort_score_vector(scores):
+    """utils::sort_score_vector (src/utils.rs:54-59); scores = [(key list, anything)]."""
+    keys = "\n".join("\t".join(k) for k, _ in scores).encode()
+    order = np.zeros(max(1, len(scores)), dtype=np.int32)
+    _hcheck(host_lib().nimble_host_sort_score_vector(keys, len(scores), order.ctypes.data))
+    return [scores[int(order[i])] for i in range(len(scores))]
 
 
 def fastq_process(input_files, libraries, output_paths):

@@ -680,7 +680,7 @@ int nimble_device_count(int *count) {
   return NIMBLE_OK;
 }
 
-int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device, nimble_index **out) {
+static int index_build_impl(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device, nimble_index **out) {
   if (!out || (!seqs && n_seqs) || !seq_off) return fail(NIMBLE_E_INVALID, "nimble_index_build: NULL argument");
   *out = nullptr;
   int ndev = 0;
@@ -689,15 +689,13 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   if (device < 0 || device >= ndev) return fail(NIMBLE_E_INVALID, "nimble_index_build: bad device ordinal");
   HIPCHK(hipSetDevice(device));
   FlatIndex fi;
-  try {
-    build_flat_index(seqs, seq_off, n_seqs, fi);
-  } catch (const std::bad_alloc &) {
-    return fail(NIMBLE_E_NOMEM, "nimble_index_build: out of host memory");
-  } catch (const std::exception &e) {
-    return fail(NIMBLE_E_INTERNAL, e.what());
-  }
+  build_flat_index(seqs, seq_off, n_seqs, fi);
   nimble_index *ix = new (std::nothrow) nimble_index();
   if (!ix) return fail(NIMBLE_E_NOMEM, "out of memory");
+  struct Guard {  // (whatever leaves this function early, by return or by exception, takes the half-built index with it)
+    nimble_index *p;
+    ~Guard() { delete p; }
+  } guard{ix};
   ix->device = device;
   ix->n_kmers = fi.n_kmers;
   ix->n_nodes = fi.n_nodes;
@@ -709,10 +707,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   const uint64_t dyn_ids = env_u64("NIMBLE_DYN_IDS", 1ULL << 26);
   const uint64_t cls_cap = fi.n_colours + dyn_classes;
   const uint64_t ids_cap = fi.col_ids.size() + dyn_ids;
-  if (cls_cap >= 0xFFFFFFF0ULL || ids_cap >= 0xFFFFFFF0ULL) {
-    delete ix;
-    return fail(NIMBLE_E_INVALID, "class table capacity exceeds 32 bits");
-  }
+  if (cls_cap >= 0xFFFFFFF0ULL || ids_cap >= 0xFFFFFFF0ULL) return fail(NIMBLE_E_INVALID, "class table capacity exceeds 32 bits");
   int rc = NIMBLE_OK;
   auto up = [&](auto &buf, const auto &vec, size_t min_elems = 0) {
     if (rc == NIMBLE_OK) rc = upload(buf, vec, &ix->device_bytes, min_elems);
@@ -746,10 +741,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   up(ix->b_intern, intern);
   std::vector<uint32_t> dyn_state = {(uint32_t)fi.n_colours, (uint32_t)fi.col_ids.size(), 0, 0};
   up(ix->b_dyn_state, dyn_state);
-  if (rc != NIMBLE_OK) {
-    delete ix;
-    return rc;
-  }
+  if (rc != NIMBLE_OK) return rc;
   ix->h_col_off = std::move(fi.col_off);
   ix->h_col_ids = std::move(fi.col_ids);
   DevIndex &d = ix->dev;
@@ -772,7 +764,7 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   // block; classes beyond that keep the colour list); NIMBLE_LDS_WINDOW=0 switches it off
   d.window_words = 0;
   if (d.all_bitmaps && fi.max_bitmap_words > 4 && env_u64("NIMBLE_LDS_WINDOW", 1) != 0)
-    d.window_words = (uint32_t)std::min<uint64_t>(fi.max_bitmap_words, env_u64("NIMBLE_LDS_WINDOW_WORDS", 32));
+    d.window_words = (uint32_t)std::min<uint64_t>(fi.max_bitmap_words, std::min<uint64_t>(env_u64("NIMBLE_LDS_WINDOW_WORDS", 32), 64));  // (64 words = 128 KiB per block: the most that leaves room for any key)
   d.cls_desc = ix->b_cls_desc.as<uint4>();
   d.cls_off = ix->b_cls_off.as<uint32_t>();
   d.cls_ids = ix->b_cls_ids.as<uint32_t>();
@@ -783,8 +775,23 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   d.intern = ix->b_intern.as<uint64_t>();
   d.intern_mask = islots - 1;
   d.dyn_state = ix->b_dyn_state.as<uint32_t>();
+  guard.p = nullptr;
   *out = ix;
   return NIMBLE_OK;
+}
+
+// (the whole build sits inside the try: the host vectors of the upload and of the intern table allocate too, and nothing
+// may be thrown across the C ABI)
+int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, int device, nimble_index **out) {
+  try {
+    return index_build_impl(seqs, seq_off, n_seqs, device, out);
+  } catch (const std::bad_alloc &) {
+    return fail(NIMBLE_E_NOMEM, "nimble_index_build: out of host memory");
+  } catch (const std::exception &e) {
+    return fail(NIMBLE_E_INTERNAL, e.what());
+  } catch (...) {
+    return fail(NIMBLE_E_INTERNAL, "nimble_index_build: unknown failure");
+  }
 }
 
 int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t s[5]) {
@@ -1033,8 +1040,12 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   const int nm = paired ? 2 : 1;
   const uint32_t kw = (max_len * (uint32_t)nm + 31u) / 32u;
   // the walk keeps every key of a tile in LDS; one workgroup may take up to 160 KiB on gfx950
-  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 > 160 * 1024)
-    return fail(NIMBLE_E_INVALID, "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~2400)");
+  // (an index with wide allele families adds its per-lane row window: DevIndex.window_words words of every lane)
+  const size_t window_bytes = c->ix->dev.all_local ? 0 : (size_t)c->ix->dev.window_words * 256 * 8;
+  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 + window_bytes > 160 * 1024)
+    return fail(NIMBLE_E_INVALID, window_bytes ? "nimble_call: reads too long for the LDS-resident walk beside this index's row "
+                                                 "window (set NIMBLE_LDS_WINDOW_WORDS lower, or NIMBLE_LDS_WINDOW=0)"
+                                               : "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~2400)");
   if (ext && ext->key_words != kw) return fail(NIMBLE_E_INVALID, "packed buffers: key_words does not match max_len");
   CallBuffers &cb = c->cb;
   cb.n = n;
@@ -2043,15 +2054,19 @@ struct nimble_comm {
     } st;
   };
   std::vector<Shard> shard;
+  // nimble_comm_abort: a rank that failed OUTSIDE the collectives (a host-side fault of its driver thread) will never
+  // arrive; the barriers stop holding anybody and every agreement ends in an error, so the other ranks come home
+  bool aborted = false;
   void barrier() {
     std::unique_lock<std::mutex> lock(mu);
+    if (aborted) return;
     const uint64_t gen = generation;
     if (++arrived == n) {
       arrived = 0;
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lock, [&] { return generation != gen; });
+      cv.wait(lock, [&] { return generation != gen || aborted; });
     }
   }
   // every rank reports its status; all of them leave with the worst one
@@ -2062,6 +2077,10 @@ struct nimble_comm {
     for (int r = 0; r < n; ++r)
       if (status[r] != NIMBLE_OK) worst = status[r];
     barrier();
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (aborted && worst == NIMBLE_OK) worst = NIMBLE_E_INTERNAL;
+    }
     return worst;
   }
 };
@@ -2131,6 +2150,14 @@ void nimble_comm_free(nimble_comm *c) {
 }
 
 int nimble_comm_size(const nimble_comm *c) { return c ? c->n : 0; }
+void nimble_comm_abort(nimble_comm *c) {
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->aborted = true;
+  }
+  c->cv.notify_all();
+}
 int nimble_comm_uses_rccl(const nimble_comm *c) { return c && c->rccl ? 1 : 0; }
 
 int nimble_counts_allreduce(nimble_comm *c, int rank, int64_t *counts_dev, uint64_t len, void *stream) {

@@ -8,6 +8,7 @@
 //   * dictionary k-mer -> (unitig, offset); edges of a unitig = unitigs starting/ending with the
 //     neighbour k-mer of its terminal k-mers
 #include "flat_index.h"
+#include "threads.h"
 
 #include <algorithm>
 #include <atomic>
@@ -41,32 +42,19 @@ struct PhaseTimer {
   }
 };
 
+// threads of the build: the CPUs this process may really use (affinity mask, cgroup quota -- a container granted 16 of a
+// host's 256 CPUs reads 256 from hardware_concurrency()), at most 32; NIMBLE_INDEX_THREADS overrides.  The reference
+// takes the number from its caller (`num_cores`, src/bin/main.rs:121-128).
 unsigned build_threads() {
   if (const char *e = getenv("NIMBLE_INDEX_THREADS")) return (unsigned)std::max(1, atoi(e));
-  unsigned h = std::thread::hardware_concurrency();
-  return h == 0 ? 1u : std::min(h, 32u);
+  return std::min(threads::usable_cpus(), 32u);
 }
 
-// fn(t) on `threads` threads
+// fn(t) for t in [0, threads): on threads of their own where the system starts them, on the calling thread where it does
+// not (csrc/threads.h -- a refused thread start must not take the process down)
 template <class F>
-void parallel_threads(unsigned threads, F fn) {
-  if (threads <= 1) {
-    fn(0u);
-    return;
-  }
-  std::vector<std::thread> th;
-  std::vector<std::exception_ptr> err(threads);
-  for (unsigned t = 0; t < threads; ++t)
-    th.emplace_back([&, t] {
-      try {
-        fn(t);
-      } catch (...) {
-        err[t] = std::current_exception();
-      }
-    });
-  for (auto &x : th) x.join();
-  for (auto &e : err)
-    if (e) std::rethrow_exception(e);
+void parallel_threads(unsigned n_threads, F fn) {
+  threads::run_indexed(n_threads, fn);
 }
 
 // fn(t, lo, hi) over [0, n) in `threads` contiguous slices (slice t = [n t / threads, n (t+1) / threads))

@@ -222,6 +222,44 @@ Coercer::Coercer(const reference_library::Reference &ref, const AlignFilterConfi
   for (size_t k = 0; k < n_all; ++k) I.rank[order[k]] = (uint32_t)k;
 }
 
+std::vector<std::pair<std::string, bool>> Coercer::parse_calls(const std::vector<std::string> &calls) const {
+  const Impl &I = *impl_;
+  const std::string sep = reference_library::SPECIAL_REVCOMP_FEATURE_NAME_SEPARATOR;
+  std::vector<std::pair<std::string, bool>> out;
+  for (const auto &c : calls) {
+    auto it = I.ids.find(c);
+    if (it != I.ids.end() && it->second < I.parse_rev.size() && (I.parse_rev[it->second] || I.parse_sid[it->second] == it->second)) {
+      out.emplace_back(I.strs[I.parse_sid[it->second]], I.parse_rev[it->second] != 0);  // (the table coerce() reads)
+    } else if (ends_with(c, "rev")) {
+      out.emplace_back(trim_end_matches(trim_end_matches(c, "rev"), sep), true);
+    } else {
+      out.emplace_back(c, false);
+    }
+  }
+  return out;
+}
+
+std::vector<uint32_t> Coercer::unmap(const std::vector<std::string> &feature_list) const {
+  const Impl &I = *impl_;
+  std::vector<uint32_t> out;
+  for (const auto &f : feature_list) {
+    auto it = I.ids.find(f);
+    if (it == I.ids.end() || I.first_row[it->second] < 0) throw Panic("Feature not found in reference columns");
+    out.push_back((uint32_t)I.first_row[it->second]);
+  }
+  return out;
+}
+
+std::vector<std::string> Coercer::feature_list(const std::vector<uint32_t> &cls, bool ignore_group_rollup) const {
+  const Impl &I = *impl_;
+  for (uint32_t r : cls)
+    if (r >= I.n_rows) throw Panic("index out of bounds: equivalence class row beyond the reference");
+  std::vector<uint32_t> sids = ignore_group_rollup ? I.names_of(cls) : I.rollup(cls);
+  std::vector<std::string> out;
+  for (uint32_t sid : sids) out.push_back(I.strs[sid]);
+  return out;
+}
+
 std::vector<std::string> Coercer::coerce(bool has1, const std::vector<uint32_t> &c1, bool has2,
                                          const std::vector<uint32_t> &c2, FilterReason &triage) const {
   const Impl &I = *impl_;
@@ -652,25 +690,17 @@ static CallOutput finish_calls(uint64_t n_reads, PseudoAligner &index, const ref
       }
       std::vector<std::vector<std::string>> sets(fresh.size());
       std::vector<FilterReason> tri(fresh.size());
-      const unsigned threads = std::max(1u, std::min(parse::usable_cpus(), 32u));
+      const unsigned n_threads = std::max(1u, std::min(parse::usable_cpus(), 32u));
       std::atomic<size_t> next{0};
-      std::vector<std::thread> pool;
-      std::vector<std::exception_ptr> err(threads);
-      for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([&, t] {
-          try {
-            for (size_t i = next.fetch_add(256); i < fresh.size(); i = next.fetch_add(256))
-              for (size_t j = i; j < std::min(fresh.size(), i + 256); ++j) {
-                const uint64_t e = fresh[j];
-                sets[j] = memo.coercer->coerce(c1[e] != NIMBLE_CLASS_NONE, *k1[j], c2[e] != NIMBLE_CLASS_NONE, *k2[j], tri[j]);
-              }
-          } catch (...) {
-            err[t] = std::current_exception();
+      // (work-sharing over an atomic cursor: every task runs the same loop, so tasks whose thread the system refused simply
+      // run on this thread -- csrc/threads.h)
+      threads::run_indexed(n_threads, [&](unsigned) {
+        for (size_t i = next.fetch_add(256); i < fresh.size(); i = next.fetch_add(256))
+          for (size_t j = i; j < std::min(fresh.size(), i + 256); ++j) {
+            const uint64_t e = fresh[j];
+            sets[j] = memo.coercer->coerce(c1[e] != NIMBLE_CLASS_NONE, *k1[j], c2[e] != NIMBLE_CLASS_NONE, *k2[j], tri[j]);
           }
-        });
-      for (auto &th : pool) th.join();
-      for (auto &x : err)
-        if (x) std::rethrow_exception(x);
+      });
       for (size_t i = 0; i < fresh.size(); ++i) {  // into the memo in histogram order, as the serial loop would
         const uint64_t e = fresh[i];
         const uint64_t key = ((uint64_t)c1[e] << 32) | c2[e];
@@ -932,9 +962,7 @@ align::CallOutput call(const align::ReadBatch &sequences, const align::ReadBatch
   align::CallOutput out = align::get_calls(sequences, mate_sequences, reference_index, reference, aligner_config,
                                            want_per_read);
   out.materialize();
-  // utils::sort_score_vector (utils.rs:54-59): Vec<String> ordering, byte-wise per string
-  std::sort(out.rows.begin(), out.rows.end(),
-            [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+  utils::sort_score_vector(out.rows);  // (utils.rs:54-59, called at score.rs:42)
   return out;
 }
 
@@ -943,8 +971,7 @@ align::CallOutput call_packed(const nimble_packed &in, uint64_t n, uint32_t max_
                               const align::AlignFilterConfig &aligner_config) {
   align::CallOutput out = align::get_calls_packed(in, n, max_len, reference_index, reference, aligner_config);
   out.materialize();
-  std::sort(out.rows.begin(), out.rows.end(),
-            [](const align::ScoreRow &a, const align::ScoreRow &b) { return a.first < b.first; });
+  utils::sort_score_vector(out.rows);
   return out;
 }
 }  // namespace score

@@ -127,6 +127,26 @@ struct Reader::Impl {
     }
     return NOT_A_MEMBER;  // a gzip member without the BGZF size field
   }
+  bool producer_dead = false;  // the producer ended with an exception: nothing more will come (under mu)
+  void producer_failed(const char *what) {
+    std::shared_ptr<Chunk> ch;
+    try {
+      ch = std::make_shared<Chunk>();
+      ch->error = std::string("Error -- could not read BAM file (") + what + ")";
+      ch->last = true;
+    } catch (...) {
+      ch.reset();  // (not even that much memory: the consumer is told through producer_dead alone)
+    }
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      producer_dead = true;
+      try {
+        if (ch && !quit) queue.push_back(std::move(ch));
+      } catch (...) {
+      }
+    }
+    cv.notify_all();
+  }
   void produce(unsigned helpers) {
     std::vector<uint8_t> comp;
     size_t have = 0;
@@ -207,20 +227,20 @@ struct Reader::Impl {
           }
           z.next_in = comp.data() + m.at + m.data_at;
           z.avail_in = (uInt)(m.size - m.data_at - 8);
-          z.next_out = ch->data.data() + m.out_at;
+          // (a member that holds no data -- the 28-byte BGZF end-of-file marker -- may be the only member of a batch: the
+          // batch's buffer is then empty and its data() null, which zlib refuses as an output pointer)
+          Bytef nothing = 0;
+          Bytef *const dst = m.isize ? ch->data.data() + m.out_at : &nothing;
+          z.next_out = dst;
           z.avail_out = m.isize;
           const int rc = inflate(&z, Z_FINISH);
-          const bool ok = rc == Z_STREAM_END && z.avail_out == 0 &&
-                          (uint32_t)crc32(0, ch->data.data() + m.out_at, m.isize) == m.crc;
+          const bool ok = rc == Z_STREAM_END && z.avail_out == 0 && (uint32_t)crc32(0, dst, m.isize) == m.crc;
           inflateEnd(&z);
           if (!ok) mark_bad(i);
         }
       };
       if (ms.size() > 4 && helpers > 1) {
-        std::vector<std::thread> ts;
-        for (unsigned t = 1; t < helpers; ++t) ts.emplace_back(work);
-        work();
-        for (auto &t : ts) t.join();
+        threads::run_beside(helpers - 1, work);
       } else {
         work();
       }
@@ -306,10 +326,7 @@ struct Reader::Impl {
             }
           };
           if (ch->recs.size() > 1024 && helpers > 1) {
-            std::vector<std::thread> ts;
-            for (unsigned t = 1; t < helpers; ++t) ts.emplace_back(describe);
-            describe();
-            for (auto &t : ts) t.join();
+            threads::run_beside(helpers - 1, describe);
           } else {
             describe();
           }
@@ -378,8 +395,9 @@ struct Reader::Impl {
       if (ended) return false;
       const auto tw = std::chrono::steady_clock::now();
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return !queue.empty(); });
+      cv.wait(lk, [&] { return !queue.empty() || producer_dead; });
       waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      if (queue.empty()) throw Panic("Error -- could not read BAM file (the reader thread failed)");
       cur = std::move(queue.front());
       queue.pop_front();
       cur_at = 0;
@@ -415,7 +433,17 @@ Reader::Reader(const std::string &path) : impl_(new Impl()) {
     unsigned helpers = std::max(1u, std::min(parse::usable_cpus() / 2, 8u));
     if (const char *e = getenv("NIMBLE_BGZF_THREADS")) helpers = (unsigned)std::max(1, atoi(e));
     Impl *im = impl_.get();
-    impl_->producer = std::thread([im, helpers] { im->produce(helpers); });
+    // (nothing thrown inside the producer may reach the top of its thread -- that is std::terminate: it is handed to the
+    // consumer as the input's error, like a damaged block)
+    impl_->producer = std::thread([im, helpers] {
+      try {
+        im->produce(helpers);
+      } catch (const std::exception &e) {
+        im->producer_failed(e.what());
+      } catch (...) {
+        im->producer_failed("unknown failure");
+      }
+    });
   } else {
     fclose(impl_->fp);
     impl_->fp = nullptr;
@@ -1029,7 +1057,13 @@ class GzWriter {
     if (!f_) throw Panic("could not create " + path);
     static const unsigned char head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
     fwrite(head, 1, 10, f_);
-    for (unsigned t = 0; t < std::max(1u, threads); ++t) workers_.emplace_back([this] { work(); });
+    for (unsigned t = 0; t < std::max(1u, threads); ++t)
+      if (!workers_.spawn([this] { work(); })) break;  // (fewer deflate threads than asked for: slower, not wrong)
+    if (workers_.size() == 0) {
+      fclose(f_);
+      f_ = nullptr;
+      throw Panic("could not start a thread for the gzip writer (thread limit reached)");
+    }
   }
   void write(const char *p, size_t n) {
     cur_.append(p, n);
@@ -1043,8 +1077,7 @@ class GzWriter {
       stop_ = true;
     }
     cv_.notify_all();
-    for (auto &w : workers_) w.join();
-    workers_.clear();
+    workers_.join();
     unsigned char tail[8];
     for (int k = 0; k < 4; ++k) {
       tail[k] = (unsigned char)(crc_ >> (8 * k));
@@ -1103,10 +1136,7 @@ class GzWriter {
           if (!fine) good = false;
         }
       };
-      std::vector<std::thread> ts;
-      for (unsigned t = 1; t < std::max(1u, threads); ++t) ts.emplace_back(work);
-      work();
-      for (auto &t : ts) t.join();
+      threads::run_beside(std::max(1u, threads) - 1, work);
     }
     unsigned char tail[8];
     if (good && fread(tail, 1, 8, f) == 8) {
@@ -1192,7 +1222,7 @@ class GzWriter {
   int level_ = 6;  // flate2's Compression::default()
   std::string cur_;
   std::vector<std::unique_ptr<Job>> jobs_;
-  std::vector<std::thread> workers_;
+  threads::Group workers_;
   std::mutex mu_;
   std::condition_variable cv_;
   size_t next_ = 0, written_ = 0;
@@ -1249,10 +1279,7 @@ void parallel_indices(size_t n, unsigned threads, F &&body) {
     }
   };
   const unsigned t = (unsigned)std::min<size_t>(std::max(1u, threads), n);
-  std::vector<std::thread> ts;
-  for (unsigned k = 1; k < t; ++k) ts.emplace_back(work);
-  work();
-  for (auto &th : ts) th.join();
+  threads::run_beside(t - 1, work);
   if (failed) throw Panic(what);
 }
 

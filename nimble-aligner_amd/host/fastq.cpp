@@ -440,7 +440,13 @@ class ParallelPlain {
     t = (unsigned)std::min<size_t>(t, n_chunks_);
     window_ = 2 * (size_t)t + 1;
     results_.resize(n_chunks_);
-    for (unsigned i = 0; i < t; ++i) workers_.emplace_back([this] { work(); });
+    for (unsigned i = 0; i < t; ++i)
+      if (!workers_.spawn([this] { work(); })) break;  // (fewer parser threads than asked for: slower, not wrong)
+    if (workers_.size() == 0) {  // (the destructor does not run for a constructor that throws)
+      if (mapped_) munmap((void *)data_, size_);
+      if (fd_ >= 0) close(fd_);
+      throw Panic("could not start a FASTQ parser thread (thread limit reached)");
+    }
   }
   ~ParallelPlain() {
     {
@@ -448,7 +454,7 @@ class ParallelPlain {
       stop_ = true;
     }
     cv_.notify_all();
-    for (auto &w : workers_) w.join();
+    workers_.join();
     if (mapped_) munmap((void *)data_, size_);
     if (fd_ >= 0) close(fd_);
   }
@@ -648,7 +654,7 @@ class ParallelPlain {
   const uint8_t *data_ = nullptr;
   size_t size_ = 0, base_ = 0, chunk_ = 0, n_chunks_ = 0, window_ = 0;
   std::vector<std::unique_ptr<Batch>> results_, pool_;
-  std::vector<std::thread> workers_;
+  threads::Group workers_;
   std::mutex mu_;
   std::condition_variable cv_;
   size_t claimed_ = 0, delivered_ = 0, true_start_ = 0;
@@ -795,7 +801,6 @@ class ParallelGz {
             from = to;
           }
         }
-        std::vector<std::thread> th;
         std::atomic<size_t> nextt{0};
         auto body = [&] {
           for (size_t i = nextt++; i < tasks.size(); i = nextt++) {
@@ -804,9 +809,7 @@ class ParallelGz {
           }
         };
         const unsigned nt = (unsigned)std::min<size_t>(threads_, std::max<size_t>(tasks.size(), 1));
-        for (unsigned i = 1; i < nt; ++i) th.emplace_back(body);
-        body();
-        for (auto &t : th) t.join();
+        threads::run_beside(nt - 1, body);
         for (const Task &t : tasks) {
           crc = (uint32_t)crc32_combine(crc, t.crc, (z_off_t)(t.to - t.from));
           member_len += t.to - t.from;
@@ -1246,19 +1249,9 @@ namespace {
 // run f(rank) on one thread per rank and wait for all of them; the first exception is re-thrown here
 template <class F>
 void on_every_rank(int world, F f) {
-  std::vector<std::thread> th;
-  std::vector<std::exception_ptr> err((size_t)world);
-  for (int r = 0; r < world; ++r)
-    th.emplace_back([&, r] {
-      try {
-        f(r);
-      } catch (...) {
-        err[(size_t)r] = std::current_exception();
-      }
-    });
-  for (auto &t : th) t.join();
-  for (auto &e : err)
-    if (e) std::rethrow_exception(e);
+  // (the ranks meet in collectives: all of them run, or none does -- csrc/threads.h)
+  if (!threads::run_all_or_none((unsigned)world, [&](unsigned r) { f((int)r); }))
+    throw Panic("could not start one thread per rank (thread limit reached)");
 }
 
 void check_dev(int rc, const char *what) {

@@ -19,6 +19,9 @@ int guarded(F &&f) {
   } catch (const std::exception &e) {
     g_err = e.what();
     return -1;
+  } catch (...) {  // (nothing is thrown across the C ABI, whatever it is)
+    g_err = "unknown failure";
+    return -1;
   }
 }
 
@@ -26,6 +29,35 @@ std::string join_tab(const std::vector<std::string> &v) {
   std::string s;
   for (size_t i = 0; i < v.size(); ++i) {
     if (i) s.push_back('\t');
+    s += v[i];
+  }
+  return s;
+}
+
+std::vector<std::string> split_on(const char *s, char sep, bool keep_single_empty) {
+  std::vector<std::string> v;
+  if (!s || (!*s && !keep_single_empty)) return v;
+  std::string cur;
+  for (const char *p = s; *p; ++p) {
+    if (*p == sep) {
+      v.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  v.push_back(cur);
+  return v;
+}
+int copy_text(const std::string &j, char *out, int cap) {
+  if ((int)j.size() + 1 > cap) throw Panic("output buffer too small");
+  memcpy(out, j.c_str(), j.size() + 1);
+  return (int)j.size();
+}
+std::string join_nl(const std::vector<std::string> &v) {
+  std::string s;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (i) s.push_back('\n');
     s += v[i];
   }
   return s;
@@ -70,6 +102,25 @@ int nimble_library_parse(const char *text, int strand_filter, nimble_library **o
     l->cfg = pr.first;
     l->ref = std::move(pr.second);
     *out = l;
+  });
+}
+int nimble_library_from_table(int n_cols, const char *const *headers, const int *rows_of, const char *const *cells,
+                              int group_on, int sequence_name_idx, int sequence_idx, nimble_library **out) {
+  *out = nullptr;
+  return guarded([&] {
+    if (n_cols < 0 || group_on < 0 || sequence_name_idx < 0 || sequence_idx < 0) throw Panic("nimble_library_from_table: bad argument");
+    std::unique_ptr<nimble_library> l(new nimble_library());
+    size_t at = 0;
+    for (int c = 0; c < n_cols; ++c) {
+      l->ref.headers.push_back(headers[c]);
+      l->ref.columns.emplace_back();
+      for (int r = 0; r < rows_of[c]; ++r) l->ref.columns.back().push_back(cells[at++]);
+    }
+    l->ref.group_on = (size_t)group_on;
+    l->ref.sequence_name_idx = (size_t)sequence_name_idx;
+    l->ref.sequence_idx = (size_t)sequence_idx;
+    l->cfg.max_hits_to_report = 10;  // (a default config: the table is what the caller is after)
+    *out = l.release();
   });
 }
 void nimble_library_free(nimble_library *l) { delete l; }
@@ -630,6 +681,49 @@ int nimble_host_coerce(const nimble_library *l, int has1, const uint32_t *c1, in
     triage = (int)t;
   });
   return rc ? -1 : triage;
+}
+int nimble_host_parse_calls(const nimble_library *l, const char *calls, char *out, int cap) {
+  return guarded([&] {
+    align::Coercer co(l->ref, l->cfg);
+    std::vector<std::string> lines;
+    for (const auto &c : co.parse_calls(split_on(calls, '\n', false))) lines.push_back(c.first + "\t" + (c.second ? "1" : "0"));
+    copy_text(join_nl(lines), out, cap);
+  });
+}
+int nimble_host_unmap(const nimble_library *l, const char *features, uint32_t *out, int cap) {
+  int n = -1;
+  int rc = guarded([&] {
+    align::Coercer co(l->ref, l->cfg);
+    std::vector<uint32_t> ids = co.unmap(split_on(features, '\n', false));
+    if ((int)ids.size() > cap) throw Panic("output buffer too small");
+    for (size_t i = 0; i < ids.size(); ++i) out[i] = ids[i];
+    n = (int)ids.size();
+  });
+  return rc ? -1 : n;
+}
+int nimble_host_feature_list(const nimble_library *l, const uint32_t *cls, int n, int ignore_group_rollup, char *out, int cap) {
+  return guarded([&] {
+    align::Coercer co(l->ref, l->cfg);
+    copy_text(join_nl(co.feature_list(std::vector<uint32_t>(cls, cls + n), ignore_group_rollup != 0)), out, cap);
+  });
+}
+int nimble_host_reference_sequence_data(const nimble_library *l, char *out, int cap) {
+  return guarded([&] {
+    auto data = utils::get_reference_sequence_data(l->ref);
+    std::vector<std::string> lines;
+    for (size_t i = 0; i < data.first.size(); ++i) lines.push_back(data.second[i] + "\t" + data.first[i]);
+    copy_text(join_nl(lines), out, cap);
+  });
+}
+int nimble_host_sort_score_vector(const char *keys, int n_rows, int32_t *order) {
+  return guarded([&] {
+    std::vector<std::pair<std::vector<std::string>, int32_t>> rows;
+    std::vector<std::string> lines = split_on(keys, '\n', n_rows == 1);
+    if ((int)lines.size() != n_rows) throw Panic("row count does not match");
+    for (size_t i = 0; i < lines.size(); ++i) rows.emplace_back(split_on(lines[i].c_str(), '\t', true), (int32_t)i);
+    utils::sort_score_vector(rows);
+    for (size_t i = 0; i < rows.size(); ++i) order[i] = rows[i].second;
+  });
 }
 int nimble_host_natural_lexical_cmp(const char *a, const char *b) { return utils::natural_lexical_cmp(a, b); }
 double nimble_host_shannon_entropy(const char *dna) { return utils::shannon_entropy(dna); }

@@ -19,23 +19,35 @@ namespace multi {
 
 namespace {
 
+// a rank that ended with an exception never arrives: abort() lets everybody out, and wait() says so by throwing
+struct Aborted {};
 struct Barrier {
   explicit Barrier(int n) : n_(n) {}
   void wait() {
     std::unique_lock<std::mutex> lock(mu_);
+    if (aborted_) throw Aborted();
     const uint64_t gen = gen_;
     if (++arrived_ == n_) {
       arrived_ = 0;
       ++gen_;
       cv_.notify_all();
     } else {
-      cv_.wait(lock, [&] { return gen_ != gen; });
+      cv_.wait(lock, [&] { return gen_ != gen || aborted_; });
+      if (gen_ == gen) throw Aborted();
     }
+  }
+  void abort() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      aborted_ = true;
+    }
+    cv_.notify_all();
   }
   std::mutex mu_;
   std::condition_variable cv_;
   int n_, arrived_ = 0;
   uint64_t gen_ = 0;
+  bool aborted_ = false;
 };
 
 void check_dev(int rc, const char *what) {
@@ -141,22 +153,33 @@ StepsResult run_steps(std::vector<std::unique_ptr<align::PseudoAligner>> &indice
     if (r == 0) t1 = std::chrono::steady_clock::now();
     check_dev(nimble_steps_end(comm, r), "nimble_steps_end");
   };
-  std::vector<std::thread> th;
-  for (int r = 0; r < W; ++r)
-    th.emplace_back([&, r] {
-      try {
-        rank_main(r);
-      } catch (...) {
-        err[(size_t)r] = std::current_exception();
-        failed = true;
-        // (the other ranks learn of a device-side failure through the collectives' agreement; a host-side one here ends
-        // the process's run: there is no way to pull them out of a barrier)
-        std::terminate();
-      }
-    });
-  for (auto &t : th) t.join();
-  for (auto &e : err)
-    if (e) std::rethrow_exception(e);
+  // One thread per rank, all or none (csrc/threads.h).  A rank that fails takes the others out with it instead of taking
+  // the process down: a failure the collectives have agreed on (a bad argument, a full buffer, an RCCL error) is every
+  // rank's own return value already; a host-side fault of ONE rank aborts the barrier here and the communicator
+  // (nimble_comm_abort), so that the ranks waiting for it return with an error too.  The first failure is the one reported.
+  std::atomic<int> first_failed{-1};
+  const bool ran = threads::run_all_or_none((unsigned)W, [&](unsigned ur) {
+    const int r = (int)ur;
+    try {
+      rank_main(r);
+    } catch (const Aborted &) {
+      // (another rank failed first; its error is the job's)
+    } catch (...) {
+      int none = -1;
+      if (first_failed.compare_exchange_strong(none, r)) err[(size_t)r] = std::current_exception();
+      failed = true;
+      bar.abort();
+      nimble_comm_abort(comm);
+    }
+  });
+  if (!ran) throw Panic("run_steps: could not start one thread per rank (thread limit reached)");
+  if (failed) {
+    // (the communicator is freed below without draining the exchange streams: an exchange whose peer never posted its
+    // half would never end)
+    const int f = first_failed.load();
+    if (f >= 0 && err[(size_t)f]) std::rethrow_exception(err[(size_t)f]);
+    throw Panic("run_steps: a rank failed");
+  }
   StepsResult res;
   res.ms_per_step = std::chrono::duration<double, std::milli>(t1 - t0).count() / (double)steps;
   res.rccl = nimble_comm_uses_rccl(comm) != 0;

@@ -24,6 +24,8 @@
 #include <utility>
 #include <vector>
 
+#include "../csrc/threads.h"
+
 struct nimble_index;
 struct nimble_ctx;
 struct nimble_packed;
@@ -111,6 +113,12 @@ std::string revcomp(const std::string &sequence);
 double shannon_entropy(const std::string &dna);
 // lexical_sort::natural_lexical_cmp as used at align.rs:846
 int natural_lexical_cmp(const std::string &a, const std::string &b);
+// utils.rs:54-59: `scores.sort_by(|a, b| a.0.cmp(&b.0))` -- a STABLE sort on the Vec<String> key (element-wise, each
+// element byte-wise).  Rows are anything whose `.first` is the key.
+template <class Row>
+void sort_score_vector(std::vector<Row> &scores) {
+  std::stable_sort(scores.begin(), scores.end(), [](const Row &a, const Row &b) { return a.first < b.first; });
+}
 
 }  // namespace utils
 
@@ -281,6 +289,14 @@ class Coercer {
   // returns the callset (empty when triaged) and sets `triage`
   std::vector<std::string> coerce(bool has1, const std::vector<uint32_t> &c1, bool has2,
                                   const std::vector<uint32_t> &c2, FilterReason &triage) const;
+  // the pieces the reference tests on their own, through the same interned tables coerce() uses (names the reference
+  // does not hold fall back to the string rule, as in the reference):
+  // AlignmentOrientation::parse_calls (align.rs:276-285)
+  std::vector<std::pair<std::string, bool>> parse_calls(const std::vector<std::string> &calls) const;
+  // unmap (align.rs:851-864): row of the first sequence_name equal to each feature; panics on an unknown one
+  std::vector<uint32_t> unmap(const std::vector<std::string> &feature_list) const;
+  // process_equivalence_class_to_feature_list (align.rs:802-849)
+  std::vector<std::string> feature_list(const std::vector<uint32_t> &equivalence_class, bool ignore_group_rollup) const;
 
  private:
   struct Impl;

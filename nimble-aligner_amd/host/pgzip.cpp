@@ -35,41 +35,10 @@
 
 namespace nimble {
 namespace parse {
-unsigned usable_cpus() {
-  static const unsigned cached = [] {
-    unsigned n = std::thread::hardware_concurrency();
-    if (!n) n = 4;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-      const int c = CPU_COUNT(&set);
-      if (c > 0) n = std::min<unsigned>(n, (unsigned)c);
-    }
-    auto quota = [](const char *path, const char *period_path) -> double {
-      FILE *f = fopen(path, "r");
-      if (!f) return 0;
-      char a[64] = {0}, b[64] = {0};
-      const int got = fscanf(f, "%63s %63s", a, b);
-      fclose(f);
-      if (got < 1 || !strcmp(a, "max") || atof(a) <= 0) return 0;
-      double period = got >= 2 ? atof(b) : 0;
-      if (period_path) {
-        FILE *g = fopen(period_path, "r");
-        if (g) {
-          if (fscanf(g, "%63s", b) == 1) period = atof(b);
-          fclose(g);
-        }
-      }
-      return period > 0 ? atof(a) / period : 0;
-    };
-    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                               // cgroup v2
-    if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");  // v1
-    if (q > 0) n = std::min<unsigned>(n, std::max(1u, (unsigned)(q + 0.5)));
-    if (const char *e = getenv("NIMBLE_CPUS")) n = (unsigned)std::max(1, atoi(e));
-    return std::max(1u, n);
-  }();
-  return cached;
-}
+unsigned usable_cpus() { return threads::usable_cpus(); }  // (csrc/threads.h: affinity mask, cgroup quota, NIMBLE_CPUS)
+}  // namespace parse
 
+namespace parse {
 namespace pgzip {
 
 void *huge_map(size_t bytes, void **map, size_t *map_bytes) {
@@ -511,7 +480,7 @@ struct Reader::Impl {
   std::vector<std::unique_ptr<Chunk>> chunks;
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<std::thread> workers;
+  threads::Group workers;
   std::atomic<size_t> next_job{0};
   size_t in_flight_limit = 0;
   size_t consumed = 0;  // chunks the consumer has taken (workers stay at most in_flight_limit ahead)
@@ -663,7 +632,7 @@ struct Reader::Impl {
       stop = true;
     }
     cv.notify_all();
-    for (auto &w : workers) w.join();
+    workers.join();
     if (data) munmap((void *)data, size);
     if (fd >= 0) close(fd);
   }
@@ -826,7 +795,9 @@ Reader::Reader(const std::string &path, unsigned threads) : impl_(new Impl()) {
   }
   I.in_flight_limit = (size_t)I.threads + 2;
   I.window.assign(WSIZE, 0);
-  for (unsigned t = 0; t < I.threads; ++t) I.workers.emplace_back([this] { impl_->work(); });
+  for (unsigned t = 0; t < I.threads; ++t)
+    if (!I.workers.spawn([this] { impl_->work(); })) break;  // (fewer inflate threads than asked for: slower, not wrong)
+  if (I.workers.size() == 0) throw Panic("could not start a gzip reader thread (thread limit reached)");  // (~Impl cleans up)
 }
 
 Reader::~Reader() {}

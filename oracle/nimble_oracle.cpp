@@ -1178,6 +1178,43 @@ int copy_out(const std::string &s, char *out, int cap) {
   return (int)s.size();
 }
 
+
+// utils::get_reference_sequence_data (utils.rs:7-24): the sequence column as DnaStrings, the name column beside it; a name
+// column shorter than the sequence column is the reference's panic
+std::pair<std::vector<Dna>, Strs> get_reference_sequence_data(const Ref &ref) {
+  const auto &seqs = ref.columns[ref.sequence_idx];
+  const auto &names = ref.columns[ref.sequence_name_idx];
+  std::vector<Dna> dna;
+  Strs out_names;
+  size_t next_name = 0;
+  for (const auto &s : seqs) {
+    dna.push_back(Dna::from_acgt_bytes((const uint8_t *)s.data(), s.size()));
+    if (next_name >= names.size())
+      throw std::runtime_error("Error -- could not read library name after JSON parse, corrupted internal state.");
+    out_names.push_back(names[next_name++]);
+  }
+  return {dna, out_names};
+}
+
+// utils::sort_score_vector (utils.rs:54-59): `sort_by(|a, b| a.0.cmp(&b.0))` -- a STABLE sort on the Vec<String> key
+// (element-wise, each element byte-wise); returns the order as indices into the input
+std::vector<int32_t> sort_score_vector_order(const std::vector<Strs> &keys) {
+  std::vector<int32_t> order(keys.size());
+  for (size_t i = 0; i < keys.size(); ++i) order[i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return keys[(size_t)a] < keys[(size_t)b]; });
+  return order;
+}
+
+Strs split_tabs(const std::string &s) {
+  Strs v;
+  std::string cur;
+  for (char c : s) {
+    if (c == '\t') { v.push_back(cur); cur.clear(); }
+    else cur.push_back(c);
+  }
+  v.push_back(cur);
+  return v;
+}
 }  // namespace
 
 struct ora_ref { Ref r; };
@@ -1270,10 +1307,7 @@ int ora_sanity_check_config(const ora_config *c) {
 
 ora_index *ora_index_build_from_ref(const ora_ref *r) {
   try {
-    // utils::get_reference_sequence_data (utils.rs:7-24)
-    std::vector<Dna> seqs;
-    for (const auto &s : r->r.columns[r->r.sequence_idx])
-      seqs.push_back(Dna::from_acgt_bytes((const uint8_t *)s.data(), s.size()));
+    std::vector<Dna> seqs = get_reference_sequence_data(r->r).first;  // (utils.rs:7-24, as src/bin/main.rs:118 does)
     ora_index *o = new ora_index();
     o->ix = build_index(seqs);
     return o;
@@ -1408,6 +1442,40 @@ int ora_filter_orientation_on_library_chemistry(const char *seq, const char *mat
     if (copy_out(join_lines(b), out_mate, cap) < 0) return -1;
     return 0;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+int ora_parse_calls(const char *in, char *out, int cap) {
+  Strs lines;
+  for (const auto &c : parse_calls(split_lines(in))) lines.push_back(c.first + "\t" + (c.second ? "1" : "0"));
+  return copy_out(join_lines(lines), out, cap);
+}
+
+int ora_unmap(const ora_ref *r, const char *features, uint32_t *out, int cap) {
+  try {
+    std::vector<uint32_t> ids = unmap(split_lines(features), r->r);
+    if ((int)ids.size() > cap) { g_err = "output buffer too small"; return -1; }
+    for (size_t i = 0; i < ids.size(); ++i) out[i] = ids[i];
+    return (int)ids.size();
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+int ora_reference_sequence_data(const ora_ref *r, char *out, int cap) {
+  try {
+    auto data = get_reference_sequence_data(r->r);
+    Strs lines;
+    for (size_t i = 0; i < data.first.size(); ++i) lines.push_back(data.second[i] + "\t" + data.first[i].to_string());
+    return copy_out(join_lines(lines), out, cap);
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+int ora_sort_score_vector(const char *keys, int n_rows, int32_t *order) {
+  std::vector<Strs> k;
+  Strs rows = split_lines(keys);
+  if ((int)rows.size() != n_rows && !(n_rows == 0 && rows.empty())) { g_err = "row count does not match"; return -1; }
+  for (const auto &row : rows) k.push_back(split_tabs(row));
+  std::vector<int32_t> o = sort_score_vector_order(k);
+  for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
+  return 0;
 }
 
 int ora_process_class_to_features(const ora_ref *r, const ora_config *cfg, const uint32_t *cls, int n,

@@ -135,6 +135,15 @@ int ora_filter_orientation_on_library_chemistry(const char *seq, const char *mat
                                                 char *out_seq, char *out_mate, int cap);
 int ora_process_class_to_features(const ora_ref *, const ora_config *, const uint32_t *cls, int n,
                                   int ignore_rollup, char *out, int cap);
+/* AlignmentOrientation::parse_calls (align.rs:276-285): one "feature\t0|1" line per call */
+int ora_parse_calls(const char *in, char *out, int cap);
+/* unmap (align.rs:851-864): row index of every feature name (first match); -1 = the reference's panic */
+int ora_unmap(const ora_ref *, const char *features, uint32_t *out, int cap);
+/* utils::get_reference_sequence_data (utils.rs:7-24): one "name\tDnaString::to_string()" line per row; -1 = its panic */
+int ora_reference_sequence_data(const ora_ref *, char *out, int cap);
+/* utils::sort_score_vector (utils.rs:54-59) on n_rows keys ('\n'-joined rows of '\t'-joined strings): order[i] = input
+ * index of output row i */
+int ora_sort_score_vector(const char *keys, int n_rows, int32_t *order);
 
 /* ---- a1/a2/a3: score::call (src/score.rs:14-46) over in-memory reads ----
  * r1/r2: concatenated ASCII bases, off[n+1] byte offsets.  r2 may be NULL (single-end).

@@ -104,6 +104,10 @@ def lib():
             "ora_filter_read_calls_with_orientation": (i32, [cp, cp, i32]),
             "ora_filter_orientation_on_library_chemistry": (i32, [cp, cp, i32, cp, cp, i32]),
             "ora_process_class_to_features": (i32, [vp, C.POINTER(Config), C.POINTER(C.c_uint32), i32, i32, cp, i32]),
+            "ora_parse_calls": (i32, [cp, cp, i32]),
+            "ora_unmap": (i32, [vp, cp, C.POINTER(C.c_uint32), i32]),
+            "ora_reference_sequence_data": (i32, [vp, cp, i32]),
+            "ora_sort_score_vector": (i32, [cp, i32, C.POINTER(C.c_int32)]),
             "ora_call": (vp, [vp, vp, C.POINTER(Config), vp, vp, vp, vp, u64, i32, i32]),
             "ora_result_free": (None, [vp]),
             "ora_result_n_rows": (u64, [vp]),
@@ -512,6 +516,43 @@ def process_equivalence_class_to_feature_list(cls, ref, cfg, ignore_group_rollup
         raise _err()
     s = out.value.decode()
     return s.split("\n") if s else []
+
+
+def parse_calls(calls):
+    """AlignmentOrientation::parse_calls (align.rs:276-285) -> [(feature, is_rev)]"""
+    out = C.create_string_buffer(1 << 16)
+    if lib().ora_parse_calls(_lines(calls), out, len(out)) < 0:
+        raise _err()
+    s = out.value.decode()
+    return [(l.rsplit("\t", 1)[0], l.rsplit("\t", 1)[1] == "1") for l in s.split("\n")] if s else []
+
+
+def unmap(features, ref):
+    """unmap (align.rs:851-864)"""
+    out = (C.c_uint32 * max(1, len(features)))()
+    n = lib().ora_unmap(ref.h, _lines(features), out, len(out))
+    if n < 0:
+        raise _err()
+    return [int(out[i]) for i in range(n)]
+
+
+def get_reference_sequence_data(ref):
+    """utils::get_reference_sequence_data (utils.rs:7-24) -> ([DnaString::to_string()], [name])"""
+    out = C.create_string_buffer(1 << 20)
+    if lib().ora_reference_sequence_data(ref.h, out, len(out)) < 0:
+        raise _err()
+    s = out.value.decode()
+    rows = [l.split("\t") for l in s.split("\n")] if s else []
+    return [r[1] for r in rows], [r[0] for r in rows]
+
+
+def sort_score_vector(scores):
+    """utils::sort_score_vector (utils.rs:54-59); scores = [(key list, anything)]"""
+    keys = "\n".join("\t".join(k) for k, _ in scores).encode()
+    order = (C.c_int32 * max(1, len(scores)))()
+    if lib().ora_sort_score_vector(keys, len(scores), order) != 0:
+        raise _err()
+    return [scores[order[i]] for i in range(len(scores))]
 
 
 def coerce(ref, cfg, c1, c2):
