@@ -224,6 +224,21 @@ def main():
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         args.e2e_reads = 0
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: the ranks are started here, as fresh child processes
+    # of torch.distributed.run, BEFORE this process imports torch or touches a GPU (a process that has initialised the GPU
+    # must not exec or be replaced; a child is a new process).  Rank 0's JSON line comes through on stdout, the exit code
+    # is the launcher's.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.form != "native" and not args.native_child:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run
     # in order: with the launch stream, the result stream, torch's streams and RCCL's, the exchange of the multi-GPU
     # pipeline would queue behind the align kernel it is meant to overlap.  Must be set before HIP initialises.

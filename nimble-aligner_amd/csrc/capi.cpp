@@ -102,7 +102,8 @@ struct nimble_index {
   hipStream_t intern_last = nullptr;  // the stream ev_intern was last recorded on
   bool released = false;  // nimble_index_free was called while contexts were alive: the last context frees the index
   DevIndex dev{};
-  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state;
+  DevBuf b_ht, b_bitmap, b_l1, b_mleft, b_rec, b_ledge, b_unitig, b_cls_desc, b_cls_off, b_cls_ids, b_cls_bits, b_intern, b_dyn_state,
+      b_srec, b_srec_first, b_srec_base, b_srec_many;
   uint64_t device_bytes = 0;
   uint64_t n_kmers = 0, n_nodes = 0, n_static = 0, unitig_bases = 0, static_entries = 0, ht_slots = 0;
   std::vector<uint32_t> h_col_off, h_col_ids;  // host mirror of the static classes
@@ -110,7 +111,7 @@ struct nimble_index {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_intern) (void)hipEventDestroy(ev_intern);
     for (DevBuf *b : {&b_ht, &b_bitmap, &b_l1, &b_mleft, &b_rec, &b_ledge, &b_unitig, &b_cls_desc, &b_cls_off, &b_cls_ids, &b_cls_bits, &b_intern,
-                      &b_dyn_state})
+                      &b_dyn_state, &b_srec, &b_srec_first, &b_srec_base, &b_srec_many})
       b->release();
   }
 };
@@ -139,6 +140,8 @@ struct nimble_ctx {
   bool h2d_pending[2] = {false, false};  // staging slots whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
+  DevBuf b_redo, b_redo_ctl;  // redo list of the fast align launch (kernels.h CallBuffers::redo)
+  DevBuf b_tile_ctr;          // tile counters of the align launches (kernels.h CallBuffers::tile_ctr)
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
   DevBuf b_plog;
   uint32_t plog_max_len = 0;
@@ -210,7 +213,7 @@ struct nimble_ctx {
                       &b_score[0], &b_score[1], &b_mism[0], &b_mism[1], &b_cls[0], &b_cls[1], &b_dyn_off[0],
                       &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
-                      &b_state, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
+                      &b_state, &b_redo, &b_redo_ctl, &b_tile_ctr, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
                       &b_out_cnt, &b_out_seg, &b_out_rep, &b_seg, &b_alen[0], &b_alen[1], &b_skip[0], &b_skip[1], &b_qual[0],
                       &b_qual[1], &b_route, &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_hot, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
                       &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
@@ -537,6 +540,13 @@ int finish_call(nimble_ctx *c) {
   for (;;) {
     int rc = fetch_state(c);
     if (rc) return rc;
+    static const bool show_redo = env_u64("NIMBLE_DEBUG_REDO", 0) != 0;  // (development: reads the fast align launch handed on)
+    if (show_redo && c->cb.redo_ctl) {
+      uint64_t ctl[4] = {0, 0, 0, 0};
+      if (hipMemcpy(ctl, c->cb.redo_ctl, sizeof ctl, hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[nimble] align: %llu of %llu reads redone by the general walk\n", (unsigned long long)ctl[0],
+                (unsigned long long)c->cb.n);
+    }
     const uint64_t err = c->h_state[10];
     if (c->h_state[14] != 0) {
       // k_pack met offsets it could not trust (device-resident inputs are validated where they are read)
@@ -712,6 +722,27 @@ static int index_build_impl(const uint8_t *seqs, const uint64_t *seq_off, uint32
   auto up = [&](auto &buf, const auto &vec, size_t min_elems = 0) {
     if (rc == NIMBLE_OK) rc = upload(buf, vec, &ix->device_bytes, min_elems);
   };
+  // An index with stretch records names a k-mer's unitig in the dictionary by the unitig's FIRST RECORD (the fast walk then
+  // starts without asking srec_first -- one gather per read less); the general walk, which wants the unitig, asks
+  // srec_node (kernels.hip seed_node).  Decided here, where the dictionary is uploaded.
+  static const bool use_mleft_ = env_u64("NIMBLE_LOCAL_RESEED", 1) != 0;
+  static const bool use_srec_ = env_u64("NIMBLE_FAST_ALIGN", 1) != 0;
+  const bool have_srec = use_srec_ && !fi.srec.empty() && use_mleft_ && !fi.mleft.empty();
+  std::vector<uint32_t> srec_node;
+  if (have_srec) {
+    srec_node.assign(fi.srec.size() / 8, 0);
+    for (size_t nd = 0; nd < fi.n_nodes; ++nd) {
+      const uint32_t first = fi.srec_first[nd];
+      const uint32_t inf = (fi.node_rec[nd * 16] & 0xFFFFFFu) - KMER;
+      const uint32_t n_rec = std::max<uint32_t>(1u, (inf + 31u) / 32u);
+      for (uint32_t j = 0; j < n_rec; ++j) srec_node[first + j] = (uint32_t)nd;
+    }
+    for (uint64_t sl = 0; sl < fi.ht_slots; ++sl)
+      if (fi.ht[2 * sl] != HT_EMPTY) {
+        const uint64_t v = fi.ht[2 * sl + 1];
+        fi.ht[2 * sl + 1] = ((uint64_t)fi.srec_first[(uint32_t)(v >> 32)] << 32) | (uint32_t)v;
+      }
+  }
   up(ix->b_ht, fi.ht);
   up(ix->b_bitmap, fi.bitmap);
   static const bool use_l1 = env_u64("NIMBLE_FILTER_L1", 1) != 0;
@@ -719,6 +750,12 @@ static int index_build_impl(const uint8_t *seqs, const uint64_t *seq_off, uint32
   static const bool use_mleft = env_u64("NIMBLE_LOCAL_RESEED", 1) != 0;
   if (use_mleft && !fi.mleft.empty()) up(ix->b_mleft, fi.mleft);
   up(ix->b_rec, fi.node_rec);
+  if (have_srec) {
+    up(ix->b_srec, fi.srec);
+    up(ix->b_srec_first, srec_node);  // (record -> unitig: the dictionary holds records)
+    up(ix->b_srec_base, fi.srec_base);
+    up(ix->b_srec_many, fi.srec_many);
+  }
   up(ix->b_ledge, fi.node_ledge);
   up(ix->b_unitig, fi.unitig);
   std::vector<uint32_t> len(fi.n_colours);
@@ -755,6 +792,10 @@ static int index_build_impl(const uint8_t *seqs, const uint64_t *seq_off, uint32
   d.mleft_log2 = fi.mleft_log2;
   d.node_rec = ix->b_rec.as<uint4>();
   d.node_ledge = ix->b_ledge.as<uint4>();
+  d.srec = have_srec ? ix->b_srec.as<uint4>() : nullptr;
+  d.srec_node = have_srec ? ix->b_srec_first.as<uint32_t>() : nullptr;
+  d.srec_base = have_srec ? ix->b_srec_base.as<uint32_t>() : nullptr;
+  d.srec_many = have_srec ? ix->b_srec_many.as<uint4>() : nullptr;
   d.unitig = ix->b_unitig.as<uint64_t>();
   d.all_local = fi.all_classes_local ? 1u : 0u;
   d.uniform_windows = (fi.uniform_windows && env_u64("NIMBLE_UNIFORM_WINDOWS", 1) != 0) ? 1u : 0u;
@@ -1064,6 +1105,8 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   }
   need(c->b_slot, nn * 4);
   need(c->b_counted, nn);
+  need(c->b_tile_ctr, 2 * (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE + 4 * 8);  // (+ the redo list's control words)
+  if (c->ix->dev.srec) need(c->b_redo, nn * 4);  // (the fast align launch's redo list: indexes with stretch records)
   for (int m = 0; m < 2; ++m) {
     if (!records && (!ext || (m == 1 && !ext->len[1]))) {
       need(c->b_len[m], nn * 4);
@@ -1149,6 +1192,9 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
   cb.hist_mask = c->hist_slots - 1;
   cb.state = c->b_state.as<uint64_t>();
+  cb.redo = c->b_redo.p ? c->b_redo.as<uint32_t>() : nullptr;
+  cb.tile_ctr = c->b_tile_ctr.as<uint64_t>();
+  cb.redo_ctl = cb.redo ? cb.tile_ctr + 2 * (size_t)TILE_COUNTERS * (TILE_COUNTER_STRIDE / 8) : nullptr;
   c->prm = *p;
   if (c->prm.min_read_length == 0) c->prm.min_read_length = 40;
   c->dslots = dslots;
@@ -1391,7 +1437,7 @@ int nimble_route_records(nimble_ctx *c, const nimble_packed *in, uint64_t n, uin
   uint64_t *block_first = c->b_route.as<uint64_t>();
   uint64_t *totals = block_first + cells;
   uint32_t *block_counts = reinterpret_cast<uint32_t *>(totals + 256);
-  CallBuffers v;
+  CallBuffers v{};
   packed_view(v, in, n);
   launch_route(c->stream, v, world, block_counts, block_first, totals, records);
   HIPCHK(hipGetLastError());
@@ -1412,7 +1458,7 @@ int nimble_unpack_records(nimble_ctx *c, const uint64_t *records, uint64_t n, co
   if (n && (!out->keys || !out->hash || !out->len[0] || !out->pre[0] || (out->paired && (!out->len[1] || !out->pre[1]))))
     return fail(NIMBLE_E_INVALID, "nimble_unpack_records: packed arrays missing");
   HIPCHK(hipSetDevice(c->ix->device));
-  CallBuffers v;
+  CallBuffers v{};
   packed_view(v, out, n);
   launch_records_unpack(c->stream, records, v);
   HIPCHK(hipGetLastError());
@@ -1658,7 +1704,6 @@ constexpr uint64_t STREAM_ALIGN_READS = 1u << 18;
 static int stream_flush_align(nimble_ctx *c, bool force) {
   const uint64_t pending = c->stream_n - c->align_from;
   if (pending == 0 || (!force && pending < STREAM_ALIGN_READS)) return NIMBLE_OK;
-  HIPCHK(hipMemsetAsync((uint64_t *)c->b_state.p + 12, 0, 8, c->stream));  // tile counter of the align grid
   launch_align(c->stream, c->ix->dev, c->prm, stream_view(c, c->align_from, pending), c->want_counters, c->align_grid_pct, c->stream_cus);
   HIPCHK(hipGetLastError());
   c->align_from = c->stream_n;

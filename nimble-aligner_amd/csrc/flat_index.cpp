@@ -466,6 +466,126 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     }
   }
   timer.lap("class descriptors");
+  // Stretch records for the fast walk (flat_index.h): every unitig's bases behind its first k-mer in stretches of 32.
+  if (out.uniform_windows && n_nodes) {
+    // Order of the records = order in which a walk meets them, as far as one array can have it: what bounds the fast walk
+    // is the number of 128-byte lines a CU fetches (a line per ~4 cycles from L2, whatever part of it is used), and a read
+    // crosses five or six unitigs.  Unitigs are laid out component by component (a component = the rows of a gene family in
+    // one orientation) in topological order of the graph's edges, first come first served (Kahn's algorithm with a queue):
+    // the alternatives behind a fork lie side by side, the unitig they merge into right behind them, so a walk reads its
+    // records front to back with small gaps -- two or three lines instead of one per unitig.  (Unitigs on cycles, which no
+    // topological order reaches, follow at the end of their component.)
+    std::vector<uint32_t> order;
+    order.reserve(n_nodes);
+    {
+      std::vector<uint32_t> comp(n_nodes), indeg(n_nodes, 0);
+      for (size_t i = 0; i < n_nodes; ++i) comp[i] = (uint32_t)i;
+      auto root = [&](uint32_t x) {
+        while (comp[x] != x) {
+          comp[x] = comp[comp[x]];
+          x = comp[x];
+        }
+        return x;
+      };
+      for (size_t nd = 0; nd < n_nodes; ++nd) {
+        const uint32_t rext = (out.node_rec[nd * 16] >> 28) & 0xFu;
+        for (uint32_t b = 0; b < 4; ++b)
+          if (rext & (1u << b)) {
+            const uint32_t t = out.node_rec[nd * 16 + 8 + b];
+            ++indeg[t];
+            const uint32_t ra = root((uint32_t)nd), rb = root(t);
+            if (ra != rb) comp[ra < rb ? rb : ra] = ra < rb ? ra : rb;  // (the smallest node id names the component)
+          }
+      }
+      // members of every component, in node order
+      std::vector<uint32_t> comp_size(n_nodes, 0), comp_at(n_nodes + 1, 0), members(n_nodes);
+      for (size_t nd = 0; nd < n_nodes; ++nd) ++comp_size[root((uint32_t)nd)];
+      for (size_t c = 0; c < n_nodes; ++c) comp_at[c + 1] = comp_at[c] + comp_size[c];
+      {
+        std::vector<uint32_t> fill(comp_at.begin(), comp_at.end() - 1);
+        for (size_t nd = 0; nd < n_nodes; ++nd) members[fill[root((uint32_t)nd)]++] = (uint32_t)nd;
+      }
+      std::vector<uint8_t> placed(n_nodes, 0);
+      std::vector<uint32_t> queue;
+      for (size_t c = 0; c < n_nodes; ++c) {
+        if (!comp_size[c]) continue;
+        const uint32_t *m = &members[comp_at[c]];
+        queue.clear();
+        for (uint32_t i = 0; i < comp_size[c]; ++i)
+          if (indeg[m[i]] == 0) queue.push_back(m[i]);
+        for (size_t q = 0; q < queue.size(); ++q) {
+          const uint32_t nd = queue[q];
+          placed[nd] = 1;
+          order.push_back(nd);
+          const uint32_t rext = (out.node_rec[(size_t)nd * 16] >> 28) & 0xFu;
+          for (uint32_t b = 0; b < 4; ++b)
+            if (rext & (1u << b)) {
+              const uint32_t t = out.node_rec[(size_t)nd * 16 + 8 + b];
+              if (--indeg[t] == 0) queue.push_back(t);
+            }
+        }
+        for (uint32_t i = 0; i < comp_size[c]; ++i)
+          if (!placed[m[i]]) order.push_back(m[i]);
+      }
+    }
+    out.srec_first.resize(n_nodes);
+    uint64_t total = 0;
+    for (uint32_t nd : order) {
+      const uint32_t inf = (out.node_rec[(size_t)nd * 16] & 0xFFFFFFu) - KMER;
+      out.srec_first[nd] = (uint32_t)total;
+      total += std::max<uint32_t>(1u, (inf + 31u) / 32u);
+    }
+    if (total < (1ULL << 32)) {
+      out.srec.assign(total * 8, 0);
+      out.srec_base.assign(total, 0);
+      std::vector<uint32_t> many_at(n_nodes, 0);
+      uint32_t n_many = 0;
+      for (size_t nd = 0; nd < n_nodes; ++nd)
+        if (__builtin_popcount((out.node_rec[nd * 16] >> 28) & 0xFu) > 2) many_at[nd] = n_many++;
+      out.srec_many.assign((size_t)std::max<uint32_t>(n_many, 1u) * 4, 0);
+      parallel_slices(n_nodes, threads, [&](unsigned, size_t lo_, size_t hi_) {
+        for (size_t nd = lo_; nd < hi_; ++nd) {
+          const uint32_t *nr = &out.node_rec[nd * 16];
+          const uint32_t inf = (nr[0] & 0xFFFFFFu) - KMER, rext = (nr[0] >> 28) & 0xFu;
+          const uint32_t n_rec = std::max<uint32_t>(1u, (inf + 31u) / 32u);
+          const uint64_t seq = (uint64_t)nr[2] + KMER;  // the unitig's base 30 in the packed buffer
+          for (uint32_t j = 0; j < n_rec; ++j) {
+            uint32_t *r = &out.srec[((size_t)out.srec_first[nd] + j) * 8];
+            const uint32_t nb = std::min<uint32_t>(32u, inf - 32u * j);
+            uint64_t bases = 0;
+            for (uint32_t b = 0; b < nb; ++b) {
+              const uint64_t pos = seq + 32u * j + b;
+              bases |= ((out.unitig[pos >> 5] >> (62 - 2 * (pos & 31))) & 3ULL) << (62 - 2 * b);
+            }
+            r[2] = (uint32_t)bases;
+            r[3] = (uint32_t)(bases >> 32);
+            r[4] = nr[5];
+            r[5] = nr[6];
+            uint32_t hdr = nb | (rext << 8) | ((nr[3] & 0x7Fu) << 16);
+            if (j + 1 == n_rec) {
+              hdr |= SREC_LAST;
+              if (__builtin_popcount(rext) > 2) {  // a fork with three or four ways out: the neighbours stand in srec_many
+                hdr |= SREC_MANY;
+                r[6] = many_at[nd];
+                for (uint32_t b = 0; b < 4; ++b)
+                  if (rext & (1u << b)) out.srec_many[(size_t)many_at[nd] * 4 + b] = out.srec_first[nr[8 + b]];
+              } else {
+                uint32_t k = 0;
+                for (uint32_t b = 0; b < 4 && k < 2; ++b)
+                  if (rext & (1u << b)) r[6 + k++] = out.srec_first[nr[8 + b]];
+              }
+            }
+            r[0] = hdr;
+            r[1] = nr[1];
+            out.srec_base[(size_t)out.srec_first[nd] + j] = nr[4];
+          }
+        }
+      });
+    } else {
+      out.srec_first.clear();
+    }
+    timer.lap("stretch records");
+  }
 }
 
 }  // namespace nimble

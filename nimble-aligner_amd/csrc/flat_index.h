@@ -19,6 +19,7 @@ constexpr uint64_t HT_EMPTY = ~0ULL;
 constexpr uint32_t NODE_INLINE_BASES = 64;   // bases a node record holds inline ...
 constexpr uint32_t NODE_INLINE_FIRST = KMER;  // ... starting at this base: the walk never compares a unitig's first k-mer
                                               // (it is the seed, or the overlap with the unitig it came from)
+constexpr uint32_t SREC_LAST = 1u << 12, SREC_MANY = 1u << 13;  // stretch-record header bits (FlatIndex::srec)
 constexpr uint32_t CLS_WINDOW = 64;          // a class whose rows span < 64 is stored as base + 64-bit mask
 constexpr uint32_t CLS_MASK_FLAG = 0x80000000u;
 constexpr uint32_t CLS_BITMAP_MAX_ROWS = 1u << 16;  // widest span a static class gets a row bitmap for (8 KiB)  // set in the descriptor's len word when the mask form is valid
@@ -182,6 +183,23 @@ struct FlatIndex {
   // record is then written relative to its component's first row (same base word for every unitig a walk can hop to), and
   // the walk intersects without shifting (kernels.hip push_col)
   bool uniform_windows = false;
+  // Stretch records (round 4, the fast walk of kernels.hip): what a walk compares in a unitig -- its bases from base 30
+  // on -- cut into stretches of at most 32 bases, one 32-byte record per stretch, so that one step of the fast walk is
+  // one record = two 16-byte gathers = one compare, whatever the unitig's length.  Built only for an index with
+  // uniform_windows (class masks relative to the component's first row: a walk that follows edges needs no base row).
+  //   u32[0]    = bases in this stretch (bits 0..5) | right-extension bits of the unitig (8..11) | SREC_LAST (12): the
+  //               unitig ends with this stretch | SREC_MANY (13): more than two right edges (u32[6] is then the fork's place
+  //               in srec_many, which holds its four neighbours) | class length (16..22)
+  //   u32[1]    = colour (class id) of the unitig
+  //   u32[2..3] = the stretch's bases, first base in the highest bit pair (bases 30 + 32 j .. of the unitig, j = record)
+  //   u32[4..5] = class mask of the unitig (relative to its component's first row)
+  //   u32[6..7] = (last stretch) record index of the right neighbour behind the lowest / the other extension base
+  // The first 16 bytes are what a compare needs, the second 16 what the way out of the stretch needs.
+  // srec_first[node] = the unitig's first record; srec_base[record] = first row of the unitig's component.
+  std::vector<uint32_t> srec;        // 8 x u32 per record
+  std::vector<uint32_t> srec_first;  // per node
+  std::vector<uint32_t> srec_base;   // per record
+  std::vector<uint32_t> srec_many;   // 4 x u32 per fork with more than two ways out: the neighbour's record per extension base
   bool all_wide_have_bitmaps = true; // every static class outside the mask form has a row bitmap in cls_bits
   uint32_t max_bitmap_words = 0;     // ... and the longest of those bitmaps, in 64-row words (sizes the device's row window)
   uint64_t n_kmers = 0, n_nodes = 0, n_colours = 0, unitig_bases = 0;

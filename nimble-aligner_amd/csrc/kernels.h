@@ -27,6 +27,12 @@ struct DevIndex {
   uint32_t mleft_log2;
   const uint4 *node_rec;    // 4 x uint4 per node: {len, colour, exts, seq_start} {redge[4]} {bases 0..63} {64..127}
   const uint4 *node_ledge;
+  // stretch records of the fast walk (flat_index.h FlatIndex::srec; all NULL when the index has none: classic launch only)
+  const uint4 *srec;          // 2 x uint4 per record
+  const uint32_t *srec_node;  // per record: its unitig.  With stretch records the dictionary names a k-mer's unitig by its first
+                              // record; the general walk turns that into the unitig here (kernels.hip seed_node)
+  const uint32_t *srec_base;  // per record
+  const uint4 *srec_many;     // neighbours of the forks with more than two ways out
   const uint64_t *unitig;
   // class table: static colour classes first, device-interned intersections appended
   uint4 *cls_desc;          // {len | CLS_MASK_FLAG, base, mask lo, mask hi}; a wider static class: {len, first row,
@@ -90,11 +96,19 @@ struct CallBuffers {
   uint64_t *hist_cnt;
   uint64_t hist_mask;
   // [0..7] = counters of nimble_call_counters, [8]=scratch used [9]=unresolved interns
-  // [10]=error flags [11]=histogram entries (compaction) [12]=align tile counter
+  // [10]=error flags [11]=histogram entries (compaction) [12]=(unused since round 4: the align tile counters are tile_ctr)
   // [13]=third and later copies of a key met by the dedup sample [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len;
   // cleared by the host) [15]=duplicates met by the dedup sample
   uint64_t *state;
+  // redo list of the fast align launch (kernels.hip k_align MODE 1 / 2), both may be NULL (= classic launch only):
+  // read indices the fast launch did not handle, and 4 control words: [0] how many, [1] tile counter of the redo launch
+  uint32_t *redo;
+  uint64_t *redo_ctl;
+  // tile counters of the align launches (kernels.hip k_align): 2 x TILE_COUNTERS counters, TILE_COUNTER_STRIDE bytes apart
+  // (first half: the classic / fast launch, second half: the redo launch); zeroed by launch_align
+  uint64_t *tile_ctr;
 };
+constexpr uint32_t TILE_COUNTERS = 64, TILE_COUNTER_STRIDE = 128;
 
 enum { ERR_SCRATCH = 1, ERR_CLASS_CAP = 2, ERR_IDS_CAP = 4, ERR_HIST = 8 };
 

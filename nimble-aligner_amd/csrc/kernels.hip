@@ -405,6 +405,7 @@ struct Lane {
   // running intersection of the visited colours (mask form): window base, surviving rows, smallest class
   uint64_t acc;
   uint32_t fbase, min_len, min_col;
+  uint32_t last_rec;  // (fast walk) a stretch record of the walk: srec_base[last_rec] is the walk's fbase, fetched only if needed
   bool all_mask;
   bool keep_list;  // some class of the index is not local: keep the visited colours for the general path
   // ... unless the first visited class spans at most WIDE_ROWS rows: then the intersection is folded during the walk into
@@ -541,12 +542,12 @@ __device__ __noinline__ uint64_t ht_resolve_slow(const uint4 *__restrict__ ht, u
 
 // one direct dictionary probe at mate position pos
 __device__ __forceinline__ bool probe_direct(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t pos, uint32_t &node,
-                                             uint32_t &off) {
+                                             uint32_t &off, bool count = true) {
   const uint64_t km = lds_bits(ln.rd, base0 + pos, KMER);
   const uint64_t h = kmer_slot(km, ix.ht_log2);
   const uint4 s = ld_gather(ix.ht + h);
   const uint64_t key = u64of(s.x, s.y);
-  ln.probes++;
+  if (count) ln.probes++;
   if (key == km) { off = s.z; node = s.w; return true; }
   if (key != HT_EMPTY) {
     const uint64_t v = ht_resolve_slow(ix.ht, ix.ht_mask, km, h);
@@ -813,6 +814,10 @@ __device__ __forceinline__ uint32_t cmp_bwd(const Lane &ln, const NodeRec &nr, c
 // (WALK phase); a typical read goes through 1-3 cycles.
 // pre: result of a direct probe of position 0 already made for this mate (by the tile partition step):
 // 0 = none made, 1 = miss, 2 = hit with pre_seed = node << 32 | offset
+// the unitig a dictionary entry names: itself, or -- in an index with stretch records, whose dictionary names a unitig by its
+// first record (walk_fast) -- the record's unitig
+__device__ __forceinline__ uint32_t seed_node(const DevIndex &ix, uint32_t w) { return ix.srec_node ? ix.srec_node[w] : w; }
+
 __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed, uint32_t &coverage,
                      uint32_t &mismatches, uint32_t pre, uint64_t pre_seed PROF_ARGS) {
   ln.n_cols = 0;
@@ -841,6 +846,7 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
         // direct probe of it is a wasted fetch; the first seed of mate 1 still goes through the direct probe)
         have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, !first, first);
       }
+      if (have) node = seed_node(ix, node);
       if (!have) {
         done = true;
       } else if (first && kmer_pos >= left_thr) {  // left extension, only behind a late first seed
@@ -1027,6 +1033,217 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
   coverage = cov;
   mismatches = mm;
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// walk_fast (round 4): map_read_with_mismatch for ONE mate in its common shapes -- or nothing at all.
+//
+// walk() above is every case of the reference's walk in one loop over 64-byte unitig records, and a wave pays for every
+// case in every iteration.  This one walks the index's STRETCH RECORDS (flat_index.h: a unitig's bases behind its first
+// k-mer cut into stretches of at most 32, a 32-byte record each): one step = one record (two 16-byte gathers of one line)
+// = one compare = one way out -- the next stretch of the same unitig, or the unitig behind the read's next base.  What
+// bounds both walks is the rate at which a CU gathers DISTINCT LINES (tools/probes/chain.hip: 213 G lane-gathers a second
+// chip-wide from an L2-resident table whatever the number of chains in flight per lane, 160 G with four loads per line,
+// 58 G from beyond L2), so what counts is gathers per read.  The seed search is walk()'s (find_match); a substitution is
+// stepped over the way walk() does it (the local re-seed: the 32 bases behind it must agree along the graph, then the
+// reference's next seed is the k-mer that ends there), a read that leaves the graph searches its next seed and walks on, but
+//   * the "several left flanks" test of a stepped-over substitution is made AFTER the walk, for all of them together (it
+//     does not steer the walk: it only says whether the short cut was allowed);
+//   * a first seed late enough for the left extension, a flank test that fails: the
+//     function returns 2, the caller puts the read on the call's redo list, and walk() does the whole read in a second
+//     launch (k_align in list mode).  Nothing of such a read is kept, so the results are walk()'s, or identical to them by
+//     the argument of the local re-seed.
+// Same counters as walk(): a unitig entered or re-entered by a seed counts as a visit, a committed short cut as two probes.
+// STRICT: num_mismatches == 0 (the usual setting); otherwise a unitig tolerates `allowed` differing bases.
+// pre / pre_seed: the tile's direct probe of position 0, as for walk().  Returns 0 = no unitig visited (NoMatch), 1 = walked
+// (the lane's running intersection -- ln.acc / min_* / last_rec -- describes the visited classes), 2 = not handled.
+template <bool STRICT>
+__device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed,
+                                         uint32_t pre, uint64_t pre_seed, uint32_t &coverage, uint32_t &mismatches) {
+  constexpr uint32_t NO_TENT = 0x40000000u;
+  ln.walk_nodes = 0;
+  ln.n_cols = 0;
+  if (L < KMER) return 0;
+  const uint64_t *rd = ln.rd;
+  const uint32_t last_kmer_pos = L - KMER;
+  // ---- the first seed: the tile's direct probe, or the scan rounds from position 3 (0 for a mate nobody has probed)
+  uint32_t node = (uint32_t)(pre_seed >> 32), koff = (uint32_t)pre_seed, kmer_pos = 0;
+  bool have = pre == 2u;
+  if (pre != 0u) ln.probes++;  // (the tile's direct probe of this mate)
+  if (!have) {
+    kmer_pos = pre == 1u ? 3u : 0u;
+    have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, pre == 1u, true);
+  }
+  if (!have) return 0;
+  if (kmer_pos >= (uint32_t)(0.2 * (double)L)) return 2;  // a late first seed starts with the left extension: walk()'s
+  uint32_t cov = 0, mm = 0;
+  uint32_t nodes = 0, commits = 0;
+  uint64_t entries = 0;
+  uint64_t acc = ~0ULL;
+  uint32_t min_len = 0xFFFFFFFFu, min_col = 0, first_rec = 0;
+  uint64_t pend = 0;  // read positions (+1) of the substitutions stepped over, 16 bits each: their flank test is still owed
+  int status;         // -1 walking, 0 done, 1 not handled, 2 the next seed has to be searched from kpos
+  for (;;) {  // one seed, one forward walk
+    // the seed's k-mer is the unitig's k-mer at offset koff: what is compared next is the unitig's base 30 + koff, i.e.
+    // base o of its stretch j (o = 32 <=> that stretch is used up; koff = 0: the head of the unitig)
+    const uint32_t j = koff ? (koff - 1u) >> 5 : 0u;
+    uint32_t rec = node + j, o = koff - 32u * j;  // (the dictionary of an index with stretch records names records)
+    if (nodes == 0) first_rec = rec;
+    else if (ix.srec_base[rec] != ix.srec_base[first_rec]) acc = 0;  // a seed in another component: no row in common
+    uint32_t kpos = kmer_pos + KMER;
+    cov += KMER;
+    uint32_t seen = 0, tneed = NO_TENT, t_cov = 0;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+    bool load = true, push = true;
+    status = -1;
+    while (status < 0) {
+      if (load) {
+        // the record's first half (header, colour, bases: what the compare needs) ahead of the second (class mask,
+        // neighbours: needed behind the compare)
+        r0 = ix.srec[(size_t)rec * 2];
+        r1 = ix.srec[(size_t)rec * 2 + 1];
+        load = false;
+      }
+      const uint32_t hdr = r0.x, nb = hdr & 63u;
+      if (tneed == 0) {
+        // all 32 bases behind the substitution agree: the reference's seed is the k-mer that ends with the last of them,
+        // in this unitig -- entered the way a seed is entered (two probes: p missed, p + 3 hit; the 30 bases of the seed
+        // count, the 32 compared did not)
+        cov -= 2;
+        ++commits;
+        tneed = NO_TENT;
+        push = true;
+      }
+      bool entered = false;
+      if (push) {  // a unitig entered by a seed or along an edge (never inside a tentative stretch)
+        push = false;
+        entered = true;
+        const uint32_t l = (hdr >> 16) & 0x7Fu;
+        ++nodes;
+        if (ln.want_counters) entries += l;
+        const bool smaller = l < min_len;
+        min_len = smaller ? l : min_len;
+        min_col = smaller ? r0.y : min_col;
+        seen = 0;
+      }
+      bool prem = false;
+      uint32_t junction = 4u;
+      const uint32_t rem = nb - o, ahead = L - kpos;
+      const uint32_t lim = ahead < tneed ? ahead : tneed;
+      const uint32_t c = rem < lim ? rem : lim;
+      if (c) {
+        const uint64_t win = lds_window(rd, base0 + kpos);
+        junction = c < 32u ? (uint32_t)(win >> (62u - 2u * c)) & 3u : 4u;
+        const uint64_t x = (win ^ (u64of(r0.z, r0.w) << (2u * o))) >> (64u - 2u * c);
+        uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
+        uint32_t adv = c;
+        if (m) {
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          const bool tent = tneed < NO_TENT / 2;
+          if (STRICT || tent) {
+            const uint32_t bit = 63u - (uint32_t)__clzll((long long)m);
+            const uint32_t k = c - 1u - (bit >> 1);  // bases in front of the first differing one
+            if (tent) {
+              // a second difference inside the 32 bases: back to the first one, general search (walk(): the same)
+              kpos = (uint32_t)(pend & 0xFFFFu) - 1u;
+              cov = t_cov;
+              pend >>= 16;
+              adv = 0;
+              status = 2;
+            } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos && (pend >> 48) == 0) {
+              // the rest of this very stretch agrees: go on tentatively from here (walk(): "on")
+              t_cov = cov + k;  // (where the walk stands if the short cut does not work out: at the differing base)
+              mm += 1;
+              cov -= 1;  // (the differing base itself is not covered)
+              tneed = 32u - (c - 1u - k) + c;
+              pend = (pend << 16) | (uint64_t)(kpos + k + 1u);
+            } else {
+              prem = true;
+              mm += 1;
+              adv = k;
+            }
+          } else if (seen + cnt <= allowed) {
+            seen += cnt;
+            mm += cnt;
+          } else {  // the base that takes this unitig above `allowed` ends the compare, unaccepted
+            const uint32_t k = allowed - seen;
+            for (uint32_t t = 0; t < k; ++t) m &= ~(1ULL << (63 - __clzll((long long)m)));
+            const uint32_t bit = 63u - (uint32_t)__clzll((long long)m);
+            adv = c - 1u - (bit >> 1);
+            mm += k + 1;
+            prem = true;
+          }
+        }
+        cov += adv;
+        kpos += adv;
+        o += adv;
+        tneed -= adv;
+      }
+      acc &= entered ? u64of(r1.x, r1.y) : ~0ULL;  // (the entered unitig's class: the record's second half, here at the latest)
+      if (status < 0 && tneed != 0) {  // (a finished tentative stretch commits first, at the head of the next step)
+        const bool tent = tneed < NO_TENT / 2;
+        if (prem) {
+          status = kpos > last_kmer_pos ? 0 : 2;  // the end, or a new seed is needed
+        } else if (o < nb) {
+          status = 0;  // the read ends inside this stretch (kpos == L)
+        } else if (!(hdr & SREC_LAST)) {
+          ++rec;  // the unitig goes on
+          o = 0;
+          load = true;
+        } else if (kpos >= L && !tent) {
+          status = 0;
+        } else {  // the unitig is done: on along the read's next base (the junction base agrees by the edge's label)
+          const uint32_t nbase = junction < 4u ? junction : lds_base(rd, base0 + kpos);
+          const uint32_t rext = (hdr >> 8) & 0xFu;
+          if ((rext >> nbase) & 1u) {
+            if (hdr & SREC_MANY) rec = sel4(ix.srec_many[r1.z], nbase);  // (a fork with three or four ways out: rare)
+            else rec = (rext & ((1u << nbase) - 1u)) ? r1.w : r1.z;      // (the lowest extension base's neighbour first)
+            o = 0;
+            load = true;
+            kpos += 1;
+            cov += 1;
+            tneed -= tent ? 1u : 0u;
+            push = !tent;
+          } else if (tent) {
+            // the read leaves the graph inside the tentative stretch: back to the differing base, general search
+            kpos = (uint32_t)(pend & 0xFFFFu) - 1u;
+            cov = t_cov;
+            pend >>= 16;
+            status = 2;
+          } else {
+            status = kpos > last_kmer_pos ? 0 : 2;  // no such edge: the end, or a new seed is needed
+          }
+        }
+      }
+    }
+    if (status != 2) break;
+    // the next seed, searched the way walk() does behind a walk (the scan rounds start at kpos itself)
+    kmer_pos = kpos;
+    if (!find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, true, false)) {
+      status = 0;
+      break;
+    }
+  }
+  // the flank tests owed for the substitutions stepped over: the k-mer at p must be absent, i.e. the 29 bases behind p
+  // (the graph's, they agreed) must have one left flank only
+  for (; status == 0 && pend; pend >>= 16) {
+    const uint32_t p1 = (uint32_t)(pend & 0xFFFFu);
+    if (mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + p1, KMER - 1u))) status = 1;
+  }
+  if (status != 0) return 2;
+  ln.nodes += nodes;
+  ln.probes += 2u * commits;
+  if (ln.want_counters) ln.entries += entries;
+  ln.walk_nodes = nodes;
+  ln.acc = acc;
+  ln.last_rec = first_rec;  // (srec_base[first_rec] is the first visited unitig's first row: the walk's fbase, if anybody asks)
+  ln.fbase = 0;
+  ln.min_len = min_len;
+  ln.min_col = min_col;
+  ln.all_mask = true;
+  coverage = cov;
+  mismatches = mm;
+  return 1;
 }
 
 // general form of nodes_to_eq_class (some visited class spans 64 rows or more): smallest class first,
@@ -1232,9 +1449,14 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 // out-of-line call alone costs the walk registers around it.
 // (the instantiation for indexes with wide classes carries the register window and the general intersection: it gets
 // 80 registers, i.e. 6 waves per SIMD, instead of spilling at 64)
-template <bool PAIRED, bool COUNTERS, bool WIDE>
-__global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES) void k_align(DevIndex ix, nimble_align_params p,
+// MODE (round 4): 0 = every read through walk(), as before.  1 = the FAST launch: seeded mates go through walk_fast; a read
+// either of whose mates it does not handle is put on the call's redo list (cb.redo, cb.redo_ctl[0] = how many) with
+// nothing of it counted, and gets its results from the launch behind this one.  2 = that launch: MODE 0 over the reads of
+// the redo list (their number and the tile counter live in cb.redo_ctl; results are stored by read id).
+template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
+__global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES) / ((COUNTERS && MODE == 1) ? 2 : 1)) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
+  static_assert(!(WIDE && MODE == 1), "the fast walk is for indexes whose classes all have the mask form");
   constexpr int want_counters = COUNTERS ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
   const uint32_t tid = threadIdx.x;
@@ -1257,6 +1479,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
   ln.n_cols = ln.last_col = ln.walk_nodes = 0;
   ln.acc = 0;
   ln.fbase = ln.min_len = ln.min_col = 0;
+  ln.last_rec = 0;
   ln.all_mask = true;
   ln.keep_list = WIDE;
   ln.window_ok = false;
@@ -1270,17 +1493,60 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
                   : nullptr;
   ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
-  const uint64_t n = cb.n;
+  const uint64_t n = MODE == 2 ? cb.redo_ctl[0] : cb.n;
+  if (MODE == 2 && n == 0) return;  // (nothing was left to redo: the usual case for reads without differences)
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  unsigned long long *const tile_counter =
+      (unsigned long long *)cb.tile_ctr + (MODE == 2 ? (size_t)TILE_COUNTERS * (TILE_COUNTER_STRIDE / 8) : 0);
+  // read id of the i-th read of this launch
+  auto rid = [&](uint64_t i) -> uint64_t { return MODE == 2 ? (uint64_t)cb.redo[i] : i; };
 
   // small block-shared arrays behind the columns in the dynamic region (extern base stays 16-byte aligned)
   uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) +
                                                LDS_COLS * ALIGN_BLOCK);
   unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
+  // (fast launch) the block's queue of reads for the redo list: the region of the colour list, which an index without wide
+  // classes never uses (LDS_COLS * ALIGN_BLOCK words), its fill and the global position of a hand-over beside the tile slot.
+  // One global atomic per REDO_FLUSH queued reads: an atomic per wave and tile on the list's one counter was 150 k
+  // same-address atomics per 10 M reads -- 1.7 ms of one L2 channel (same-address atomics run at ~90 M/s).
+  uint32_t *const s_redo = reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK);
+  uint32_t &s_rcount = *reinterpret_cast<uint32_t *>(extra + 8);  // queued | handed over in this round << 16
+  uint32_t &s_rbase = *reinterpret_cast<uint32_t *>(extra + 12);
+  constexpr uint32_t REDO_FLUSH = ALIGN_BLOCK;
+  static_assert(MODE != 1 || LDS_COLS * ALIGN_BLOCK >= 2 * REDO_FLUSH, "the queue holds a hand-over's worth plus one tile's bails");
+  if (MODE == 1 && tid == 0) s_rcount = 0;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
   uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
   uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
   uint64_t prev_tile = ~0ULL;
+  // Tiles are handed out dynamically (they differ a lot in cost), but NOT through one counter: atomics on one address run
+  // at ~80 M/s on this chip whoever issues them, so an increment per 256-read tile is 39 k increments per 10 M reads =
+  // 0.5 ms of the atomic unit's time -- which a launch over reads that do nothing showed to be the whole launch
+  // (tools/probes/skeleton.hip: 0.497 ms with the counter, 0.006 ms without).  TILE_COUNTERS counters, a 128-byte line
+  // each, own a contiguous range of the tiles; a block (its thread 0) draws from the counter of its number and, when that
+  // range is used up, from the next one, and it asks for its next tile while it works on the current one (the atomic's
+  // round trip used to stand between two barriers of every tile).
+  const unsigned long long tiles_per_counter = (n_tiles + TILE_COUNTERS - 1) / TILE_COUNTERS;
+  unsigned long long next_tile = ~0ULL;     // (thread 0) the tile fetched ahead; >= n_tiles: none is left
+  uint32_t my_counter = blockIdx.x % TILE_COUNTERS, counters_tried = 0;
+  auto fetch_tile = [&]() {
+    next_tile = n_tiles;
+    while (counters_tried < TILE_COUNTERS) {
+      const unsigned long long first = (unsigned long long)my_counter * tiles_per_counter;
+      if (first < n_tiles) {  // (a small launch leaves most ranges empty: nothing to ask them)
+        const unsigned long long t = atomicAdd(tile_counter + (size_t)my_counter * (TILE_COUNTER_STRIDE / 8), 1ULL);
+        if (t < tiles_per_counter && first + t < n_tiles) {
+          next_tile = first + t;
+          return;
+        }
+      }
+      my_counter = my_counter + 1 == TILE_COUNTERS ? 0u : my_counter + 1;  // used up: on to the neighbour's range
+      ++counters_tried;
+    }
+  };
+#ifndef NIMBLE_STATIC_TILES
+  if (tid == 0) fetch_tile();
+#endif
   PROF_DECL
   for (;;) {
     // dynamic tile scheduling: tiles differ a lot in cost (off-target reads probe 41 times)
@@ -1292,8 +1558,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
     // on a permutation of the tile): written out here, every wave stores 64 consecutive reads per instruction -- whole
     // lines instead of 64 scattered words per store that leave L2 as partial lines.
     if (prev_tile != ~0ULL) {
-      const uint64_t rp = prev_tile * ALIGN_BLOCK + tid;
-      if (rp < n) {
+      const uint64_t rp_i = prev_tile * ALIGN_BLOCK + tid;
+#ifndef NIMBLE_SKEL_NOSTORE  // (experiments: the skeleton without its result stores)
+      if (rp_i < n) {
+        const uint64_t rp = rid(rp_i);
         const uint64_t rs = col[nm * ALIGN_BLOCK];
 #pragma unroll
         for (int m = 0; m < nm; ++m) {
@@ -1304,35 +1572,71 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
           st_stream(&cb.cls[m][rp], (uint32_t)(v >> 32));
         }
       }
+#endif
     }
 #endif
-    if (tid == 0) s_tile = atomicAdd((unsigned long long *)&cb.state[12], 1ULL);
+    if (tid == 0) {
+#ifdef NIMBLE_STATIC_TILES
+      s_tile = prev_tile == ~0ULL ? (unsigned long long)blockIdx.x : prev_tile + gridDim.x;
+      (void)tile_counter;
+#else
+      s_tile = next_tile;
+#endif
+      if (MODE == 1) {
+        // hand REDO_FLUSH queued reads over to the list -- all of them when this block is about to leave
+        const uint32_t q = s_rcount & 0xFFFFu, give = s_tile >= n_tiles ? q : (q >= REDO_FLUSH ? REDO_FLUSH : 0u);
+        if (give) s_rbase = (uint32_t)atomicAdd((unsigned long long *)&cb.redo_ctl[0], (unsigned long long)give);
+        s_rcount = (q - give) | (give << 16);  // (the entries handed over are the queue's last `give`)
+      }
+    }
     __syncthreads();
     const uint64_t tile = s_tile;
+    if (MODE == 1) {
+      const uint32_t left = s_rcount & 0xFFFFu, give = s_rcount >> 16;
+      for (uint32_t k = tid; k < give; k += ALIGN_BLOCK) cb.redo[(uint64_t)s_rbase + k] = s_redo[left + k];
+      // (the next tile's bails are appended behind `left` only after the partition's barriers below)
+    }
     PROF(0)
     if (tile >= n_tiles) break;
+#ifndef NIMBLE_STATIC_TILES
+    if (tid == 0) fetch_tile();  // (consumed at the head of the next round)
+#endif
     prev_tile = tile;
     // ---- own slot: key into LDS column tid, first direct probe of mate 0
-    const uint64_t r_own = tile * ALIGN_BLOCK + tid;
+    const uint64_t i_own = tile * ALIGN_BLOCK + tid;
+    const uint64_t r_own = i_own < n ? rid(i_own) : 0;
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
     uint64_t seedv = ~0ULL;
-    if (r_own < n) {
+    if (i_own < n) {
+      // Everything the tile needs from memory is asked for at once: the key words do not wait for the lengths (what lies
+      // behind a key is masked when the lengths are there).  A tile is a chain of dependent round trips -- tile index,
+      // lengths, key words, first probe, the walk's records -- and a block does nothing else meanwhile: a launch over reads
+      // that stop at the prefilter, which fetches and stores 70 bytes a read, took 0.5 of k_align's 1.2 ms.
+      const uint32_t pre0 = rd_pre(cb, 0, r_own);
       const uint32_t k0 = rd_len(cb, 0, r_own);
       const uint32_t l1 = nm == 2 ? rd_len(cb, 1, r_own) : 0u;
-      const uint32_t nw = (k0 + l1 + 31u) >> 5;
       const uint32_t l0 = rd_alen(cb, 0, r_own);  // bases of mate 0 that are aligned
-      if (cb.rec) {
-        const uint64_t *row = cb.rec + r_own * cb.rec_words;
-        for (uint32_t w = 0; w < kw; ++w) col[w * ALIGN_BLOCK] = w < nw ? row[w] : 0ULL;
-      } else {
-        for (uint32_t w = 0; w < kw; ++w)
-          col[w * ALIGN_BLOCK] = w < nw ? ld_stream(cb.keys + (uint64_t)w * cb.key_stride + r_own) : 0ULL;
+      constexpr uint32_t KCH = 8;
+      const uint64_t *row = cb.rec ? cb.rec + r_own * cb.rec_words : nullptr;
+      for (uint32_t w0 = 0; w0 < kw; w0 += KCH) {
+        uint64_t v[KCH];
+#pragma unroll
+        for (uint32_t j = 0; j < KCH; ++j)
+#ifdef NIMBLE_SKEL_NOKEYS  // (experiments: the skeleton without its key loads)
+          v[j] = 0ULL;
+#else
+          v[j] = w0 + j < kw ? (row ? row[w0 + j] : ld_stream(cb.keys + (uint64_t)(w0 + j) * cb.key_stride + r_own)) : 0ULL;
+#endif
+        const uint32_t nw = (k0 + l1 + 31u) >> 5;
+#pragma unroll
+        for (uint32_t j = 0; j < KCH; ++j)
+          if (w0 + j < kw) col[(w0 + j) * ALIGN_BLOCK] = w0 + j < nw ? v[j] : 0ULL;
       }
       col[kw * ALIGN_BLOCK] = 0ULL;
-      if (rd_pre(cb, 0, r_own) == R_TODO && l0 >= KMER) {
+      if (pre0 == R_TODO && l0 >= KMER) {
         uint32_t nd = 0, of = 0;
         ln.rd = col;
-        if (probe_direct(ix, ln, 0u, 0u, nd, of)) {
+        if (probe_direct(ix, ln, 0u, 0u, nd, of, MODE != 1)) {  // (the fast launch counts a read's probes when the read is done)
           kind = 1;
           seedv = u64of(of, nd);
         } else {
@@ -1370,8 +1674,9 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
     }
     PROF(2)
     const uint32_t slot = s_perm[tid];
-    const uint64_t r = tile * ALIGN_BLOCK + slot;
-    const bool active = r < n;
+    const uint64_t r_i = tile * ALIGN_BLOCK + slot;
+    const bool active = r_i < n;
+    const uint64_t r = active ? rid(r_i) : 0;
     ln.rd = lds64 + slot;
     const uint64_t pre_seed = s_seed[slot];
     uint32_t L[2] = {0, 0};   // aligned bases per mate
@@ -1384,6 +1689,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
       }
     }
     bool any_walk = false;
+    // (fast launch) a read that bails leaves no trace in the work counters: they are taken back to where the read began
+    bool bail = false, pre_counted = false;
+    const uint32_t probes_r0 = ln.probes, nodes_r0 = ln.nodes;
+    const uint64_t entries_r0 = ln.entries;
     uint64_t res_v[2] = {0, 0}, res_r = 0;  // (staged results: score | mismatches << 16 | class << 32 per mate; reasons)
     for (int m = 0; m < nm; ++m) {
       uint32_t reason = NIMBLE_R_NONE, score = 0, mm = 0, cls = CLS_NONE;
@@ -1397,14 +1706,27 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
         uint32_t pre = rd_pre(cb, m, r);
         if (pre != R_TODO) {
           reason = pre;
-          if (m == 0) c_pre++;
+          if (m == 0) pre_counted = true;
+        } else if (MODE == 1 && bail) {
+          // (mate 0 put the read on the redo list already)
         } else {
           uint32_t cov = 0, mis = 0;
           const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
           PROF(3)
-          bool some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed PROF_PASS);
+          bool some;
+          if (MODE == 1) {
+            const uint32_t base0 = m ? mate1_at : 0u;
+            const int w = p.num_mismatches == 0 ? walk_fast<true>(ix, ln, base0, L[m], 0u, pre_state, pre_seed, cov, mis)
+                                                : walk_fast<false>(ix, ln, base0, L[m], p.num_mismatches, pre_state, pre_seed, cov, mis);
+            some = w == 1;
+            bail = w == 2;
+          } else {
+            some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed PROF_PASS);
+          }
           PROF(3)
-          if (!some) {
+          if (MODE == 1 && bail) {
+            // nothing of this read is kept
+          } else if (!some) {
             reason = NIMBLE_R_NO_MATCH;
           } else {
             any_walk = true;
@@ -1416,7 +1738,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
             // the class is spelled out (hash, mask form) only when it is needed: a walk in the register window knows its
             // size from four popcounts, and a result of the size of the smallest visited class IS that class
             const bool windowed = WIDE && !ln.all_mask && ln.window_ok;
-            count = windowed ? window_count(ln) : finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
+            // (fast launch: the class's size is a popcount; its first row -- one more line from the index -- is fetched only
+            // when the class is not simply the smallest visited one, below)
+            count = MODE == 1 ? (uint32_t)__popcll(ln.acc)
+                              : (windowed ? window_count(ln) : finish_class<WIDE>(ix, ln, dhash, nullptr, mres));
             // `score as f64 / len as f64 >= score_percent` (align.rs:968, filter/align.rs:16) as an exact
             // integer test: min_cov[len] is the smallest score whose IEEE quotient reaches score_percent
             if (p.discard_nonzero_mismatch && mis != 0) {
@@ -1434,6 +1759,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
                   // in the register window against the stored ids); only a class never seen before goes through the
                   // claim / verify kernels
                   cls = CLS_PENDING;
+                  if (MODE == 1) {
+                    ln.fbase = ix.srec_base[ln.last_rec];
+                    finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
+                  }
                   if (windowed) finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
                   if (mres.is_mask || windowed) {
                     const uint32_t tag = intern_tag(dhash);
@@ -1508,6 +1837,26 @@ __global__ __launch_bounds__(ALIGN_BLOCK, WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : 
       c[nm * ALIGN_BLOCK] = res_r;
     }
 #endif
+    if (MODE == 1) {
+      // the reads this launch did not handle go on the redo list (one atomic per wave); what they left in the lane's work
+      // counters is taken back, and whatever was staged for them above is overwritten by the launch that redoes them
+      const uint64_t bm = __ballot(active && bail);
+      if (bm) {  // into the block's queue (an LDS atomic per wave); handed over to the list at the head of a later tile
+        const uint32_t lane = tid & 63u, leader = (uint32_t)__ffsll((long long)bm) - 1u;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&s_rcount, (uint32_t)__popcll(bm)) & 0xFFFFu;
+        at = __shfl(at, (int)leader, 64);
+        if (active && bail) s_redo[at + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = (uint32_t)r;
+      }
+      if (bail) {
+        ln.probes = probes_r0;
+        ln.nodes = nodes_r0;
+        ln.entries = entries_r0;
+        pre_counted = false;
+        any_walk = false;
+      }
+    }
+    if (pre_counted) c_pre++;
     if (any_walk) c_seeded++;
   }
 #if NIMBLE_PROFILE_SECTIONS
@@ -2243,30 +2592,23 @@ static int resident_blocks(const void *fn, size_t lds, int *cus_out) {
   return per_cu;
 }
 
-static const void *align_kernel(bool paired, bool counters, bool wide) {
-#define NIMBLE_PICK(K) \
-  (paired ? (counters ? (wide ? (const void *)K<true, true, true> : (const void *)K<true, true, false>)    \
-                      : (wide ? (const void *)K<true, false, true> : (const void *)K<true, false, false>)) \
-          : (counters ? (wide ? (const void *)K<false, true, true> : (const void *)K<false, true, false>)  \
-                      : (wide ? (const void *)K<false, false, true> : (const void *)K<false, false, false>)))
-  return NIMBLE_PICK(k_align);
+// mode: 0 = the classic launch, 1 = the fast launch (indexes without wide classes only), 2 = the redo launch behind it
+static const void *align_kernel(bool paired, bool counters, bool wide, int mode) {
+#define NIMBLE_PICK(P, C)                                                                                        \
+  (mode == 1 ? (const void *)k_align<P, C, false, 1>                                                              \
+             : mode == 2 ? (const void *)k_align<P, C, false, 2>                                                  \
+                         : (wide ? (const void *)k_align<P, C, true, 0> : (const void *)k_align<P, C, false, 0>))
+  return paired ? (counters ? NIMBLE_PICK(true, true) : NIMBLE_PICK(true, false))
+                : (counters ? NIMBLE_PICK(false, true) : NIMBLE_PICK(false, false));
 #undef NIMBLE_PICK
 }
 
-void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct, int n_cus) {
-  if (cb.n == 0) return;
-  uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  const bool wide = ix.all_local == 0;
-  const uint32_t nm = cb.paired ? 2u : 1u;
-  const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
-  const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
-  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
-                     (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
-  const void *fn = align_kernel(cb.paired != 0, want_counters != 0, wide);
-  // persistent blocks: exactly as many as are resident at once (a larger grid would run a second, nearly
-  // empty round); tiles are handed out through a counter.  Residency and the opt-in to more dynamic LDS than the
-  // default limit (long reads) are per device and per kernel: rank threads of a sharded call launch concurrently.
+// one launch of an align kernel: a persistent grid of exactly as many blocks as are resident at once (a larger grid
+// would run a second, nearly empty round), tiles handed out through a counter; `want_blocks` caps the grid (0 = no cap)
+static void launch_align_kernel(hipStream_t s, const void *fn, size_t lds, const DevIndex &ix, const nimble_align_params &p,
+                                const CallBuffers &cb, uint64_t tiles, int grid_pct, int n_cus, uint64_t want_blocks) {
+  // Residency and the opt-in to more dynamic LDS than the default limit (long reads) are per device and per kernel:
+  // rank threads of a sharded call launch concurrently.
   int dev = 0;
   (void)hipGetDevice(&dev);
   static std::mutex mu;
@@ -2290,9 +2632,37 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   // kernels of another stream (RCCL's exchange) waiting until it ends
   uint64_t resident = (uint64_t)resident_blocks_now * (uint64_t)(grid_pct < 10 ? 10 : (grid_pct > 100 ? 100 : grid_pct)) / 100;
   if (resident < 1) resident = 1;
-  uint32_t grid = (uint32_t)(tiles < resident ? tiles : resident);
+  uint64_t grid = tiles < resident ? tiles : resident;
+  if (want_blocks && grid > want_blocks) grid = want_blocks;
   void *args[] = {(void *)&ix, (void *)&p, (void *)&cb};
-  (void)hipLaunchKernel(fn, dim3(grid), dim3(ALIGN_BLOCK), args, lds, s);
+  (void)hipLaunchKernel(fn, dim3((uint32_t)grid), dim3(ALIGN_BLOCK), args, lds, s);
+}
+
+void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters, int grid_pct, int n_cus) {
+  if (cb.n == 0) return;
+  const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  const bool wide = ix.all_local == 0;
+  const uint32_t nm = cb.paired ? 2u : 1u;
+  const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
+  const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
+  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
+                     (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
+  // Indexes whose classes all have the mask form take the FAST launch (walk_fast: the common shapes of a walk, lean)
+  // followed by the launch that redoes, through walk(), the reads the fast one put on the call's redo list -- a few per
+  // cent of them.  NIMBLE_FAST_ALIGN=0, an index with wide classes, or a context without a redo list: the classic launch.
+  static const bool fast_on = !(getenv("NIMBLE_FAST_ALIGN") && atoi(getenv("NIMBLE_FAST_ALIGN")) == 0);
+  // (both launches' tile counters and, right behind them, the redo list's control words: one fill)
+  (void)hipMemsetAsync(cb.tile_ctr, 0, 2 * (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE + 4 * sizeof(uint64_t), s);
+  if (fast_on && !wide && ix.srec && ix.mleft && cb.redo && cb.redo_ctl) {
+    launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 1), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
+    // (how many reads the list holds is known on the device only: a grid for an eighth of the reads; the blocks take
+    // tiles of the list until it is empty, most of them none)
+    launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 2), lds, ix, p, cb, tiles, grid_pct, n_cus,
+                        tiles / 16 + 1);
+    return;
+  }
+  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, 0), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
 }
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
