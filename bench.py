@@ -411,6 +411,29 @@ def main():
     per = [1000.0 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]
     steady = per[1:] if len(per) > 2 else per
 
+    # ---- multi-GPU (torch form): the merged table of the LAST step against ONE call over the union of the ranks' reads of
+    # that step, run on rank 0 (after the timed region; the native form checks itself the same way).  A failure here is
+    # reported in the line, it never takes the line down.
+    union_parity = None
+    if sharded and not paired:
+        try:
+            mine = sets[(args.steps - 1) % n_sets][0]
+            parts = [mine]
+            if world > 1:
+                parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+                dist.gather(mine, parts, dst=0)
+            if rank == 0:
+                union = torch.cat(parts, dim=0).contiguous() if world > 1 else mine
+                torch.cuda.synchronize()
+                want = lib.score_call_raw(union, None, None, None, n=world * n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE).to_list()
+                got = reducer.rows(*rows)
+                norm = lambda t: sorted((tuple(f), int(c)) for f, c in t)
+                union_parity = ("bit-exact table (%d rows) vs one call over the %d reads of all ranks" % (len(got), world * n)
+                                if norm(got) == norm(want) else "MISMATCH")
+                del union
+        except Exception as ex:
+            union_parity = "not checked: %s" % str(ex)[:200]
+
     fam = T // wl["family"]
     out = {
         "metric": "reads/sec aligned (whole job), counts bit-exact vs the CPU path",
@@ -441,6 +464,8 @@ def main():
         },
         # (the pipelined multi-GPU form hands steps back in bursts -- the drain returns two at once -- so its smallest
         # interval says nothing; it is left out there)
+        "rccl": bool(sharded and dist.get_backend() == "nccl") if sharded else None,
+        "parity_on_union": union_parity,
         "step_ms": {"min": None if (sharded and not args.no_pipeline) else min(steady),
                     "median": statistics.median(steady), "max": max(steady),
                     "note": "host interval between successive completed steps (the first, which carries the pipeline fill, "

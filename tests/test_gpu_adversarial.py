@@ -308,12 +308,36 @@ import os  # noqa: E402
 import subprocess  # noqa: E402
 import sys  # noqa: E402
 
+@pytest.mark.gpu
+def test_ordinary_work_after_the_adversarial_ones():
+    """Runs last in the child process that holds all four (below): a library built, its index built (the native call the
+    round-3 suite aborted in), calls made -- in a process that carries whatever the four left behind."""
+    import json
+    for features in (16, 60):
+        names, seqs = synth.make_library(features)
+        reads = synth.make_reads(seqs, 8192, seed=features)
+        lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index(0)
+        a = lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)
+        b = lib.score_call(reads.reshape(-1), None, n=reads.shape[0], fixed_len=150)
+        assert a == b and len(a) > 0
+
+
 _ISOLATED = ("test_device_offsets_are_validated_on_the_device", "test_two_streams_intern_the_same_new_classes",
              "test_index_freed_before_its_context",
              "test_a_stale_hip_error_of_another_library_does_not_fail_a_healthy_call")
 if os.environ.get("NIMBLE_TEST_CHILD") != "1":
-    for _name in _ISOLATED:
+    for _name in _ISOLATED + ("test_ordinary_work_after_the_adversarial_ones",):
         globals()[_name].__test__ = False
+
+    def test_the_four_in_one_process_then_ordinary_work():
+        """... and once all four in ONE process, followed by ordinary work in that same process: the process-wide state they
+        leave is still exercised (isolation alone would hide what it was introduced to survive)."""
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        ids = [os.path.abspath(__file__) + "::" + c for c in _ISOLATED + ("test_ordinary_work_after_the_adversarial_ones",)]
+        cp = subprocess.run([sys.executable, "-m", "pytest"] + ids + ["-q", "-m", "gpu", "-x", "-p", "no:randomly"],
+                            env=dict(os.environ, NIMBLE_TEST_CHILD="1"), capture_output=True, text=True, timeout=1200, cwd=root)
+        assert cp.returncode == 0 and "5 passed" in cp.stdout, cp.stdout[-3000:] + cp.stderr[-3000:]
+    test_the_four_in_one_process_then_ordinary_work = pytest.mark.gpu(test_the_four_in_one_process_then_ordinary_work)
 
     @pytest.mark.parametrize("case", _ISOLATED)
     def test_in_a_process_of_its_own(case):

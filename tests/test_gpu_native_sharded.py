@@ -269,3 +269,40 @@ def test_pipelined_native_steps_equal_one_call_over_the_union(lib_and_reads, dev
     want = oracle_tsv(path, "unstranded", r1[sel], r2[sel] if paired else None)
     got = "feature\tscore\n" + "".join("\t".join(f) + "\t%d\n" % c for f, c in rows.to_list())
     assert got == want
+
+
+def test_rank_threads_that_cannot_be_started_are_an_error_not_an_abort(lib_and_reads):
+    """Round 3's native driver ended the process (std::terminate) when a rank failed; a thread the system refuses for one
+    of the ranks must come back as an ordinary error of nimble_multi_steps / the sharded FASTQ pipeline -- all ranks or
+    none (csrc/threads.h run_all_or_none), nobody left in a barrier.  In a child process: the refusal hook is process-wide."""
+    import subprocess
+    import sys
+    import textwrap
+    path, names, seqs, r1, r2, f1, f2, d = lib_and_reads
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch
+        nim = importlib.import_module("nimble-aligner_amd")
+        synth = importlib.import_module("nimble-aligner_amd.synth")
+        path, f1 = %r, %r
+        libs = [nim.Library(path, "unstranded").build_index(0) for _ in range(2)]
+        a = torch.zeros((4000, 150), dtype=torch.uint8, device="cuda:0") + 65
+        torch.cuda.synchronize()
+        try:
+            nim.multi_steps(libs, [0, 0], [[a.data_ptr()], [a.data_ptr()]], None, 4000, 150, 1, 2)
+            print("STEPS RAN")
+        except nim.Panic as e:
+            print("STEPS PANIC", e)
+        try:
+            nim.fastq_process_sharded([f1], nim.Library(path, "unstranded"), [0, 0], %r)
+            print("SHARDED RAN")
+        except nim.Panic as e:
+            print("SHARDED PANIC", e)
+    """) % (root, path, f1, str(d / "refused.tsv"))
+    env = dict(os.environ, NIMBLE_FAIL_SPAWN_AT="1", NIMBLE_INDEX_THREADS="1", NIMBLE_CPUS="1")
+    cp = subprocess.run([sys.executable, "-c", body], env=env, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, (cp.returncode, cp.stdout[-2000:], cp.stderr[-2000:])   # never SIGABRT
+    assert "STEPS PANIC" in cp.stdout and "thread" in cp.stdout, cp.stdout[-2000:]
+    assert "SHARDED PANIC" in cp.stdout or "SHARDED RAN" in cp.stdout, cp.stdout[-2000:]

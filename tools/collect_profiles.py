@@ -29,8 +29,17 @@ head = ("# rocprofv3 --pmc <one group per pass> --kernel-trace -- python3 bench.
         "# FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE tallies 128-B requests at 64 B on gfx950 (double it).\n"
         % bench["config"]["workload"])
 open(os.path.join(dst, rnd + "_pmc_summary.txt"), "w").write(head + summary)
-blk = re.search(r"^k_align<false, false(?:, false)?>\n((?:  .*\n)+)", summary, re.M)
-vals = dict(re.findall(r"^\s+(\S+)\s+avg/dispatch\s+(\S+)", blk.group(1), re.M)) if blk else {}
+# the align stage of a call: one launch (k_align<false, false, false[, 0]>) or, since round 4, the fast launch and the launch that
+# redoes what it left (k_align<..., 1> and <..., 2>): their counters add up to the stage's
+vals, launches = {}, []
+for name in ("k_align<false, false, false>", "k_align<false, false, false, 0>", "k_align<false, false, false, 1>",
+             "k_align<false, false, false, 2>"):
+    blk = re.search(r"^" + re.escape(name) + r"\n((?:  .*\n)+)", summary, re.M)
+    if not blk:
+        continue
+    launches.append(name)
+    for k, v in re.findall(r"^\s+(\S+)\s+avg/dispatch\s+(\S+)", blk.group(1), re.M):
+        vals[k] = vals.get(k, 0.0) + float(v)
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     fetch, write = float(vals["FETCH_SIZE"]) * 1024, float(vals["WRITE_SIZE"]) * 1024
     t = {"reads": bench["config"]["reads_per_gpu"], "features": bench["config"]["features"],
@@ -39,6 +48,8 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
          "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
          "correction": "2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE; memory-side of L2, "
                        "Infinity-Cache hits included",
+         "launches_summed": launches,
+         "sq_insts_valu": vals.get("SQ_INSTS_VALU"), "tcc_miss": vals.get("TCC_MISS_sum"), "tcc_hit": vals.get("TCC_HIT_sum"),
          "source": "profiles/%s_pmc_summary.txt" % rnd}
     json.dump(t, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
     print(json.dumps(t))
