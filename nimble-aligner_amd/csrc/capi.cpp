@@ -183,7 +183,9 @@ struct nimble_ctx {
   std::vector<uint32_t> h_seg, h_rep;
   uint64_t scratch_cap = 0;
   uint64_t hist_slots = 0;
-  hipEvent_t ev[7] = {};
+  hipEvent_t ev[9] = {};  // [0..6] stage marks of a call, [7] the first align launch has ended, [8] its redo launch starts
+  bool redo_timed = false;  // ... and the last call had one (nimble_call_timing_align)
+  bool redo_owed = false;  // the fast align launch of the call being enqueued has not had its redo launch yet (enqueue_tail)
   bool have_events = false;
   bool called = false;
   int want_counters = 0;
@@ -417,16 +419,17 @@ int enqueue_route(nimble_ctx *c) {
 
 // One round of class interning (claim, then verify behind the kernel boundary), chained behind the interning of
 // every other context of the index (see nimble_index::ev_intern).
-int enqueue_intern_round(nimble_ctx *c, int round) {
+int enqueue_intern_round(nimble_ctx *c, int round, hipStream_t on = nullptr) {
   nimble_index *ix = c->ix;
+  hipStream_t s = on ? on : c->stream;
   std::lock_guard<std::mutex> lock(ix->intern_mu);
   if (!ix->ev_intern) HIPCHK(hipEventCreateWithFlags(&ix->ev_intern, hipEventDisableTiming));
-  if (ix->intern_chained) HIPCHK(hipStreamWaitEvent(c->stream, ix->ev_intern, 0));
-  launch_intern_claim(c->stream, ix->dev, c->cb, round);
-  launch_intern_verify(c->stream, ix->dev, c->cb);
-  HIPCHK(hipEventRecord(ix->ev_intern, c->stream));
+  if (ix->intern_chained) HIPCHK(hipStreamWaitEvent(s, ix->ev_intern, 0));
+  launch_intern_claim(s, ix->dev, c->cb, round);
+  launch_intern_verify(s, ix->dev, c->cb);
+  HIPCHK(hipEventRecord(ix->ev_intern, s));
   ix->intern_chained = true;
-  ix->intern_last = c->stream;
+  ix->intern_last = s;
   return NIMBLE_OK;
 }
 
@@ -453,6 +456,16 @@ int enqueue_head(nimble_ctx *c) {
 int enqueue_tail(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
+  // the redo launch of a fast align launch: the general walk over the few per cent of reads the fast one left.  (On the side
+  // stream beside the next call's pack it got in the way of the next fast launch: step 2.074 against 2.09 ms, every
+  // kernel beside it longer -- profiles/r04_experiments.txt 9 -- so it stays on the launch stream.)
+  HIPCHK(hipEventRecord(c->ev[7], s));
+  c->redo_timed = c->redo_owed;
+  if (c->redo_owed) {
+    HIPCHK(hipEventRecord(c->ev[8], s));
+    launch_align_redo(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus);
+    c->redo_owed = false;
+  }
   HIPCHK(hipEventRecord(c->ev[2], s));
   // class interning, round 0: claim, then verify behind the kernel boundary.  Tag collisions (practically
   // never) leave reads unresolved; finish_call() then runs further rounds and redoes dedup + count.
@@ -508,7 +521,7 @@ int enqueue_call(nimble_ctx *c) {
     rc = enqueue_route(c);
     if (rc) return rc;
   }
-  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus);
+  c->redo_owed = launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus, false);
   return enqueue_tail(c);
 }
 
@@ -2042,6 +2055,25 @@ int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
   out[1] = uniq;
   for (int i = 2; i <= 6; ++i) out[i] = c->h_state[i];
   out[7] = dst[0] - c->dyn_before;
+  return NIMBLE_OK;
+}
+
+int nimble_call_timing_align(nimble_ctx *c, float ms[2]) {
+  if (!c || !ms) return fail(NIMBLE_E_INVALID, "NULL argument");
+  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_call_timing_align: no call has been made");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipEventSynchronize(c->ev[5]));
+  ms[0] = ms[1] = 0.0f;
+  // (a streamed call launches its align kernels batch by batch and records no such marks: zeros)
+  if (hipEventElapsedTime(&ms[0], c->ev[1], c->ev[7]) != hipSuccess) {
+    (void)hipGetLastError();
+    ms[0] = 0.0f;
+    return NIMBLE_OK;
+  }
+  if (c->redo_timed && hipEventElapsedTime(&ms[1], c->ev[8], c->ev[2]) != hipSuccess) {
+    (void)hipGetLastError();
+    ms[1] = 0.0f;
+  }
   return NIMBLE_OK;
 }
 

@@ -120,8 +120,11 @@ void launch_pack_words(hipStream_t s, const uint64_t *w1, const uint32_t *len1, 
                        const uint32_t *len2, uint32_t stride2, uint32_t max_len, uint32_t min_len, const double *plog,
                        const CallBuffers &cb);
 // n_cus: CUs the stream may use (a CU-masked stream; 0 = the whole device): the persistent grid is sized to them
-void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct = 100, int n_cus = 0);
+// returns true when the redo launch of a fast align launch is still owed (with_redo = false; kernels.hip)
+bool launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters, int grid_pct = 100, int n_cus = 0, bool with_redo = true);
+void launch_align_redo(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                       int want_counters, int grid_pct = 100, int n_cus = 0);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid = 0);  // 0 = one thread per read

@@ -2638,31 +2638,46 @@ static void launch_align_kernel(hipStream_t s, const void *fn, size_t lds, const
   (void)hipLaunchKernel(fn, dim3((uint32_t)grid), dim3(ALIGN_BLOCK), args, lds, s);
 }
 
-void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct, int n_cus) {
-  if (cb.n == 0) return;
-  const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+static size_t align_lds(const DevIndex &ix, const CallBuffers &cb) {
   const bool wide = ix.all_local == 0;
   const uint32_t nm = cb.paired ? 2u : 1u;
   const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
   const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
-  const size_t lds = (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
-                     (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
-  // Indexes whose classes all have the mask form take the FAST launch (walk_fast: the common shapes of a walk, lean)
-  // followed by the launch that redoes, through walk(), the reads the fast one put on the call's redo list -- a few per
-  // cent of them.  NIMBLE_FAST_ALIGN=0, an index with wide classes, or a context without a redo list: the classic launch.
+  return (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
+         (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
+}
+
+// Indexes with stretch records take the FAST launch (walk_fast) followed by the launch that redoes, through walk(), the
+// reads the fast one put on the call's redo list -- a few per cent of them.  NIMBLE_FAST_ALIGN=0, an index with wide
+// classes, or a context without a redo list: the classic launch.  Returns true when the redo launch is still owed
+// (with_redo = false: the caller places it, e.g. on the side stream beside the next call's pack).
+bool launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters, int grid_pct, int n_cus, bool with_redo) {
+  if (cb.n == 0) return false;
+  const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  const bool wide = ix.all_local == 0;
+  const size_t lds = align_lds(ix, cb);
   static const bool fast_on = !(getenv("NIMBLE_FAST_ALIGN") && atoi(getenv("NIMBLE_FAST_ALIGN")) == 0);
   // (both launches' tile counters and, right behind them, the redo list's control words: one fill)
   (void)hipMemsetAsync(cb.tile_ctr, 0, 2 * (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE + 4 * sizeof(uint64_t), s);
   if (fast_on && !wide && ix.srec && ix.mleft && cb.redo && cb.redo_ctl) {
     launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 1), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
-    // (how many reads the list holds is known on the device only: a grid for an eighth of the reads; the blocks take
-    // tiles of the list until it is empty, most of them none)
-    launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 2), lds, ix, p, cb, tiles, grid_pct, n_cus,
-                        tiles / 16 + 1);
-    return;
+    if (!with_redo) return true;
+    launch_align_redo(s, ix, p, cb, want_counters, grid_pct, n_cus);
+    return false;
   }
   launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, 0), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
+  return false;
+}
+
+// the launch behind the fast one: walk() over the reads of the redo list.  How many those are is known on the device only:
+// a grid for a sixteenth of the reads; the blocks take tiles of the list until it is empty, most of them none.
+void launch_align_redo(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                       int want_counters, int grid_pct, int n_cus) {
+  if (cb.n == 0) return;
+  const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
+  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 2), align_lds(ix, cb), ix, p, cb, tiles, grid_pct,
+                      n_cus, tiles / 16 + 1);
 }
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
