@@ -336,18 +336,10 @@ def main():
         r1, r2 = sets[k % n_sets]
         lib.score_call_begin(slot, r1, None, r2, None, n=n, fixed_len=L, max_len=L, mem=nim.MEM_DEVICE)
 
-    launches = {"first": 0.0, "redo": 0.0}  # the align stage by launches (nimble_call_timing_align), summed over the steps
-
-    def add_launches(c, times=1):
-        a, b = c.timing_align()
-        launches["first"] += a * times
-        launches["redo"] += b * times
-
     def end(slot):
         r = lib.score_call_end(slot, raw=True)
         for k, v in ctxs[slot].timing().items():
             stage[k] += v
-        add_launches(ctxs[slot])
         return r
 
     stage = {k: 0.0 for k in ("pack", "align", "intern", "dedup", "count", "total")}
@@ -371,7 +363,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     stage = {k: 0.0 for k in stage}
-    launches = {k: 0.0 for k in launches}
     marks = []  # host time at which each step's rows were in hand
     t0 = time.perf_counter()
     if sharded and not args.no_pipeline:
@@ -386,14 +377,12 @@ def main():
             marks.append(time.perf_counter())
         for k, v in ctx.timing().items():
             stage[k] += v * args.steps
-        add_launches(ctx, args.steps)
     elif depth == 1:
         for i in range(args.steps):
             rows = step(i)
             marks.append(time.perf_counter())
             for k, v in ctx.timing().items():
                 stage[k] += v
-            add_launches(ctx)
     else:
         # every step is a complete score::call (begin + end); two are in flight, all K end inside the timed region
         for i in range(args.steps):
@@ -497,11 +486,7 @@ def main():
         n_call = int(counters["reads"]) if sharded else n   # reads of the launch the counters describe
         align_bytes = n_call * key_bytes + 16 * P + hit * key_bytes + 16 * U + 4 * E + 16 * n_call * nm
         pipe_bytes = n_call * L * nm + 16 * P + hit * (key_bytes + 96) + 16 * U + 4 * E + 16 * n_call * nm
-        # k_align's duration: its launches' own HIP-event durations added up -- the fast launch on the launch stream and,
-        # when the index has stretch records, the launch that redoes what it left, which with calls in flight runs on the
-        # side stream (stage_ms["align"] spans first launch to the end of the second, wait included)
-        align_launch_ms = {k: v / max(args.steps, 1) for k, v in launches.items()}
-        align_s = (align_launch_ms["first"] + align_launch_ms["redo"]) / 1000.0 or stage["align"] / 1000.0
+        align_s = stage["align"] / 1000.0
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -539,9 +524,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": align_bytes,
-            "kernel_ms": align_s * 1000.0,
-            "kernel_launches_ms": {"k_align (first launch: fast walk, or the general walk)": align_launch_ms["first"],
-                                   "k_align (redo launch: general walk over the reads the fast one left)": align_launch_ms["redo"]},
+            "kernel_ms": stage["align"],
             "bytes_per_read": align_bytes / max(n_call, 1),
             "pipeline": {"algorithmic_bytes_per_read": pipe_bytes / max(n_call, 1),
                          "achieved_GBps": pipe_bytes / (device_ms / 1000.0) / 1e9,

@@ -308,12 +308,6 @@ int nimble_call_counters(nimble_ctx *, uint64_t c[8]);
 /* Device time of the stages of the last call, measured with HIP events on the context's stream:
  * ms[0]=pack ms[1]=align ms[2]=intern ms[3]=dedup ms[4]=count ms[5]=total (first launch to last). */
 int nimble_call_timing(nimble_ctx *, float ms[6]);
-/* The align stage of the last call by launches: ms[0] = the first launch (the fast walk over the index's stretch records, or
- * the general walk when the index has none), ms[1] = the launch that redoes the reads the fast one left to the general
- * walk (0 when there was none).  With calls in flight the second one runs on the index's side stream beside the next
- * call's pack, so ms[1] of nimble_call_timing (first launch to the end of the second) also holds the wait between them;
- * these two are the launches' own durations (what the kernel trace of a profiler shows per kernel). */
-int nimble_call_timing_align(nimble_ctx *, float ms[2]);
 int nimble_ctx_synchronize(nimble_ctx *);
 
 /* Dense count vector over the first n_classes class ids, single-end convenience for multi-GPU

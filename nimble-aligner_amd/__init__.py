@@ -87,7 +87,7 @@ HIP_SYMBOLS = [
     "nimble_abi_version", "nimble_last_error", "nimble_device_count", "nimble_index_build", "nimble_index_free",
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
-    "nimble_call_timing", "nimble_call_timing_align", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
+    "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
     "nimble_call_packed", "nimble_call_words", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_append_packed", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
@@ -128,7 +128,6 @@ def hip_lib():
         L.nimble_read_records.argtypes = [vp, i32, vp, vp, vp, vp, vp, u64]
         L.nimble_call_counters.argtypes = [vp, C.POINTER(u64)]
         L.nimble_call_timing.argtypes = [vp, C.POINTER(C.c_float)]
-        L.nimble_call_timing_align.argtypes = [vp, C.POINTER(C.c_float)]
         L.nimble_key_words.argtypes = [u32, i32]
         L.nimble_key_words.restype = u32
         L.nimble_pack.argtypes = [vp, C.POINTER(AlignParams), vp, vp, vp, vp, u64, u32, u32, i32, C.POINTER(NimblePacked)]
@@ -494,12 +493,6 @@ class Context:
         t = (C.c_float * 6)()
         _check(hip_lib().nimble_call_timing(self.h, t))
         return dict(pack=t[0], align=t[1], intern=t[2], dedup=t[3], count=t[4], total=t[5])
-
-    def timing_align(self):
-        """The align stage of the last call by launches: (first launch ms, redo launch ms) -- nimble_call_timing_align."""
-        t = (C.c_float * 2)()
-        _check(hip_lib().nimble_call_timing_align(self.h, t))
-        return float(t[0]), float(t[1])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -140,7 +140,6 @@ struct nimble_ctx {
   bool h2d_pending[2] = {false, false};  // staging slots whose copy the host has not waited for yet (NIMBLE_MEM_HOST_PINNED)
   DevBuf b_keys, b_len[2], b_hash, b_pre[2], b_reason[2], b_score[2], b_mism[2], b_cls[2], b_dyn_off[2], b_dyn_len[2],
       b_dyn_hash[2], b_dyn_pos[2], b_slot, b_counted, b_scratch, b_ws, b_dedup, b_hist_keys, b_hist_cnt, b_state;
-  DevBuf b_redo, b_redo_ctl;  // redo list of the fast align launch (kernels.h CallBuffers::redo)
   DevBuf b_tile_ctr;          // tile counters of the align launches (kernels.h CallBuffers::tile_ctr)
   DevBuf b_in[2], b_in_off[2];  // staging of host inputs
   DevBuf b_plog;
@@ -183,9 +182,7 @@ struct nimble_ctx {
   std::vector<uint32_t> h_seg, h_rep;
   uint64_t scratch_cap = 0;
   uint64_t hist_slots = 0;
-  hipEvent_t ev[9] = {};  // [0..6] stage marks of a call, [7] the first align launch has ended, [8] its redo launch starts
-  bool redo_timed = false;  // ... and the last call had one (nimble_call_timing_align)
-  bool redo_owed = false;  // the fast align launch of the call being enqueued has not had its redo launch yet (enqueue_tail)
+  hipEvent_t ev[7] = {};
   bool have_events = false;
   bool called = false;
   int want_counters = 0;
@@ -215,7 +212,7 @@ struct nimble_ctx {
                       &b_score[0], &b_score[1], &b_mism[0], &b_mism[1], &b_cls[0], &b_cls[1], &b_dyn_off[0],
                       &b_dyn_off[1], &b_dyn_len[0], &b_dyn_len[1], &b_dyn_hash[0], &b_dyn_hash[1], &b_dyn_pos[0],
                       &b_dyn_pos[1], &b_slot, &b_counted, &b_scratch, &b_ws, &b_dedup, &b_hist_keys, &b_hist_cnt,
-                      &b_state, &b_redo, &b_redo_ctl, &b_tile_ctr, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
+                      &b_state, &b_tile_ctr, &b_in[0], &b_in[1], &b_in_off[0], &b_in_off[1], &b_plog, &b_min_cov, &b_out_c1, &b_out_c2,
                       &b_out_cnt, &b_out_seg, &b_out_rep, &b_seg, &b_alen[0], &b_alen[1], &b_skip[0], &b_skip[1], &b_qual[0],
                       &b_qual[1], &b_route, &b_trim_ls, &b_trim_qp, &b_hist_rep, &b_hot, &b_stage[0][0], &b_stage[0][1], &b_stage[1][0], &b_stage[1][1], &b_stage_off[0][0],
                       &b_stage_off[0][1], &b_stage_off[1][0], &b_stage_off[1][1]})
@@ -456,16 +453,6 @@ int enqueue_head(nimble_ctx *c) {
 int enqueue_tail(nimble_ctx *c) {
   hipStream_t s = c->stream;
   CallBuffers &cb = c->cb;
-  // the redo launch of a fast align launch: the general walk over the few per cent of reads the fast one left.  (On the side
-  // stream beside the next call's pack it got in the way of the next fast launch: step 2.074 against 2.09 ms, every
-  // kernel beside it longer -- profiles/r04_experiments.txt 9 -- so it stays on the launch stream.)
-  HIPCHK(hipEventRecord(c->ev[7], s));
-  c->redo_timed = c->redo_owed;
-  if (c->redo_owed) {
-    HIPCHK(hipEventRecord(c->ev[8], s));
-    launch_align_redo(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus);
-    c->redo_owed = false;
-  }
   HIPCHK(hipEventRecord(c->ev[2], s));
   // class interning, round 0: claim, then verify behind the kernel boundary.  Tag collisions (practically
   // never) leave reads unresolved; finish_call() then runs further rounds and redoes dedup + count.
@@ -521,7 +508,7 @@ int enqueue_call(nimble_ctx *c) {
     rc = enqueue_route(c);
     if (rc) return rc;
   }
-  c->redo_owed = launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus, false);
+  launch_align(s, c->ix->dev, c->prm, cb, c->want_counters, c->align_grid_pct, c->stream_cus);
   return enqueue_tail(c);
 }
 
@@ -553,13 +540,6 @@ int finish_call(nimble_ctx *c) {
   for (;;) {
     int rc = fetch_state(c);
     if (rc) return rc;
-    static const bool show_redo = env_u64("NIMBLE_DEBUG_REDO", 0) != 0;  // (development: reads the fast align launch handed on)
-    if (show_redo && c->cb.redo_ctl) {
-      uint64_t ctl[4] = {0, 0, 0, 0};
-      if (hipMemcpy(ctl, c->cb.redo_ctl, sizeof ctl, hipMemcpyDeviceToHost) == hipSuccess)
-        fprintf(stderr, "[nimble] align: %llu of %llu reads redone by the general walk\n", (unsigned long long)ctl[0],
-                (unsigned long long)c->cb.n);
-    }
     const uint64_t err = c->h_state[10];
     if (c->h_state[14] != 0) {
       // k_pack met offsets it could not trust (device-resident inputs are validated where they are read)
@@ -1118,8 +1098,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   }
   need(c->b_slot, nn * 4);
   need(c->b_counted, nn);
-  need(c->b_tile_ctr, 2 * (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE + 4 * 8);  // (+ the redo list's control words)
-  if (c->ix->dev.srec) need(c->b_redo, nn * 4);  // (the fast align launch's redo list: indexes with stretch records)
+  need(c->b_tile_ctr, (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE);
   for (int m = 0; m < 2; ++m) {
     if (!records && (!ext || (m == 1 && !ext->len[1]))) {
       need(c->b_len[m], nn * 4);
@@ -1205,9 +1184,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   cb.hist_cnt = c->b_hist_cnt.as<uint64_t>();
   cb.hist_mask = c->hist_slots - 1;
   cb.state = c->b_state.as<uint64_t>();
-  cb.redo = c->b_redo.p ? c->b_redo.as<uint32_t>() : nullptr;
   cb.tile_ctr = c->b_tile_ctr.as<uint64_t>();
-  cb.redo_ctl = cb.redo ? cb.tile_ctr + 2 * (size_t)TILE_COUNTERS * (TILE_COUNTER_STRIDE / 8) : nullptr;
   c->prm = *p;
   if (c->prm.min_read_length == 0) c->prm.min_read_length = 40;
   c->dslots = dslots;
@@ -2055,25 +2032,6 @@ int nimble_call_counters(nimble_ctx *c, uint64_t out[8]) {
   out[1] = uniq;
   for (int i = 2; i <= 6; ++i) out[i] = c->h_state[i];
   out[7] = dst[0] - c->dyn_before;
-  return NIMBLE_OK;
-}
-
-int nimble_call_timing_align(nimble_ctx *c, float ms[2]) {
-  if (!c || !ms) return fail(NIMBLE_E_INVALID, "NULL argument");
-  if (!c->called) return fail(NIMBLE_E_INVALID, "nimble_call_timing_align: no call has been made");
-  HIPCHK(hipSetDevice(c->ix->device));
-  HIPCHK(hipEventSynchronize(c->ev[5]));
-  ms[0] = ms[1] = 0.0f;
-  // (a streamed call launches its align kernels batch by batch and records no such marks: zeros)
-  if (hipEventElapsedTime(&ms[0], c->ev[1], c->ev[7]) != hipSuccess) {
-    (void)hipGetLastError();
-    ms[0] = 0.0f;
-    return NIMBLE_OK;
-  }
-  if (c->redo_timed && hipEventElapsedTime(&ms[1], c->ev[8], c->ev[2]) != hipSuccess) {
-    (void)hipGetLastError();
-    ms[1] = 0.0f;
-  }
   return NIMBLE_OK;
 }
 

@@ -100,12 +100,8 @@ struct CallBuffers {
   // [13]=third and later copies of a key met by the dedup sample [14]=input-error latch of k_pack (device-resident offsets that do not fit max_len;
   // cleared by the host) [15]=duplicates met by the dedup sample
   uint64_t *state;
-  // redo list of the fast align launch (kernels.hip k_align MODE 1 / 2), both may be NULL (= classic launch only):
-  // read indices the fast launch did not handle, and 4 control words: [0] how many, [1] tile counter of the redo launch
-  uint32_t *redo;
-  uint64_t *redo_ctl;
-  // tile counters of the align launches (kernels.hip k_align): 2 x TILE_COUNTERS counters, TILE_COUNTER_STRIDE bytes apart
-  // (first half: the classic / fast launch, second half: the redo launch); zeroed by launch_align
+  // tile counters of the align launch (kernels.hip k_align): TILE_COUNTERS counters, TILE_COUNTER_STRIDE bytes apart, zeroed by
+  // launch_align
   uint64_t *tile_ctr;
 };
 constexpr uint32_t TILE_COUNTERS = 64, TILE_COUNTER_STRIDE = 128;
@@ -120,11 +116,8 @@ void launch_pack_words(hipStream_t s, const uint64_t *w1, const uint32_t *len1, 
                        const uint32_t *len2, uint32_t stride2, uint32_t max_len, uint32_t min_len, const double *plog,
                        const CallBuffers &cb);
 // n_cus: CUs the stream may use (a CU-masked stream; 0 = the whole device): the persistent grid is sized to them
-// returns true when the redo launch of a fast align launch is still owed (with_redo = false; kernels.hip)
-bool launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct = 100, int n_cus = 0, bool with_redo = true);
-void launch_align_redo(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                       int want_counters, int grid_pct = 100, int n_cus = 0);
+void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters, int grid_pct = 100, int n_cus = 0);
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round);
 void launch_intern_verify(hipStream_t s, const DevIndex &ix, const CallBuffers &cb);
 void launch_dedup(hipStream_t s, const nimble_align_params &p, const CallBuffers &cb, uint32_t grid = 0);  // 0 = one thread per read

@@ -1046,24 +1046,22 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
 // chip-wide from an L2-resident table whatever the number of chains in flight per lane, 160 G with four loads per line,
 // 58 G from beyond L2), so what counts is gathers per read.  The seed search is walk()'s (find_match); a substitution is
 // stepped over the way walk() does it (the local re-seed: the 32 bases behind it must agree along the graph, then the
-// reference's next seed is the k-mer that ends there), a read that leaves the graph searches its next seed and walks on, but
-//   * the "several left flanks" test of a stepped-over substitution is made AFTER the walk, for all of them together (it
-//     does not steer the walk: it only says whether the short cut was allowed);
-//   * a first seed late enough for the left extension, a flank test that fails: the
-//     function returns 2, the caller puts the read on the call's redo list, and walk() does the whole read in a second
-//     launch (k_align in list mode).  Nothing of such a read is kept, so the results are walk()'s, or identical to them by
-//     the argument of the local re-seed.
+// reference's next seed is the k-mer that ends there), a read that leaves the graph searches its next seed and walks on.
+// Everything else is walk()'s, step by step: the left extension behind a late first seed (over the general walk's unitig
+// records: once per read, for one bench read in seventy), the flank test where a substitution is met, the mismatch budget
+// per unitig.  (A first form handed those reads to a second launch of the general walk through a redo list: 2.4 % of the
+// bench reads, 0.14 ms per 10 M -- the latency of that launch's hardest tile; profiles/r04_experiments.txt 3, 10.)
 // Same counters as walk(): a unitig entered or re-entered by a seed counts as a visit, a committed short cut as two probes.
 // STRICT: num_mismatches == 0 (the usual setting); otherwise a unitig tolerates `allowed` differing bases.
-// pre / pre_seed: the tile's direct probe of position 0, as for walk().  Returns 0 = no unitig visited (NoMatch), 1 = walked
-// (the lane's running intersection -- ln.acc / min_* / last_rec -- describes the visited classes), 2 = not handled.
+// pre / pre_seed: the tile's direct probe of position 0, as for walk().  Returns false = no unitig visited (NoMatch), true =
+// walked (the lane's running intersection -- ln.acc / min_* / last_rec -- describes the visited classes).
 template <bool STRICT>
-__device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed,
-                                         uint32_t pre, uint64_t pre_seed, uint32_t &coverage, uint32_t &mismatches) {
+__device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed,
+                                          uint32_t pre, uint64_t pre_seed, uint32_t &coverage, uint32_t &mismatches) {
   constexpr uint32_t NO_TENT = 0x40000000u;
   ln.walk_nodes = 0;
   ln.n_cols = 0;
-  if (L < KMER) return 0;
+  if (L < KMER) return false;
   const uint64_t *rd = ln.rd;
   const uint32_t last_kmer_pos = L - KMER;
   // ---- the first seed: the tile's direct probe, or the scan rounds from position 3 (0 for a mate nobody has probed)
@@ -1074,25 +1072,54 @@ __device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t 
     kmer_pos = pre == 1u ? 3u : 0u;
     have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, pre == 1u, true);
   }
-  if (!have) return 0;
-  if (kmer_pos >= (uint32_t)(0.2 * (double)L)) return 2;  // a late first seed starts with the left extension: walk()'s
+  if (!have) return false;
   uint32_t cov = 0, mm = 0;
   uint32_t nodes = 0, commits = 0;
   uint64_t entries = 0;
   uint64_t acc = ~0ULL;
   uint32_t min_len = 0xFFFFFFFFu, min_col = 0, first_rec = 0;
-  uint64_t pend = 0;  // read positions (+1) of the substitutions stepped over, 16 bits each: their flank test is still owed
-  int status;         // -1 walking, 0 done, 1 not handled, 2 the next seed has to be searched from kpos
+  int status;  // -1 walking, 0 done, 2 the next seed has to be searched from kpos
+  if (kmer_pos >= (uint32_t)(0.2 * (double)L)) {
+    // LEFT EXTENSION behind a late first seed, as in walk(): the read's bases in front of the seed against the unitig, and
+    // on into the left neighbours picked by the read's base, every entered neighbour a visit.  Over the general walk's
+    // unitig records (this happens once per read, for one read in seventy of the bench recipe).
+    uint32_t last_pos = kmer_pos - 1;
+    uint32_t pnode = ix.srec_node[node];  // (the dictionary names a unitig by its first record)
+    uint32_t poff = koff > 0 ? koff - 1 : 0;
+    for (;;) {
+      const NodeRec nr = load_node(ix, pnode);
+      const uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
+      bool prem;
+      const uint32_t matched = cmp_bwd(ln, nr, ix.unitig, base0 + last_pos, poff, n, allowed, mm, prem);
+      cov += matched;
+      if (last_pos + 1 - matched == 0 || prem) break;
+      last_pos -= matched;
+      const uint32_t nbase = lds_base(rd, base0 + last_pos);
+      if (!(nr_exts(nr) & (1u << nbase))) break;
+      pnode = sel4(ix.node_ledge[pnode], nbase);
+      const uint4 h0 = ix.node_rec[(size_t)pnode * 4], h1 = ix.node_rec[(size_t)pnode * 4 + 1];
+      poff = (h0.x & 0xFFFFFFu) - KMER;
+      const uint32_t l = h0.w & ~CLS_MASK_FLAG;
+      ++nodes;
+      if (ln.want_counters) entries += l;
+      const bool smaller = l < min_len;
+      min_len = smaller ? l : min_len;
+      min_col = smaller ? h0.y : min_col;
+      acc &= u64of(h1.y, h1.z);  // (class masks are relative to the component's first row, and a neighbour is of the component)
+    }
+  }
+  bool first_seed = true;
   for (;;) {  // one seed, one forward walk
     // the seed's k-mer is the unitig's k-mer at offset koff: what is compared next is the unitig's base 30 + koff, i.e.
     // base o of its stretch j (o = 32 <=> that stretch is used up; koff = 0: the head of the unitig)
     const uint32_t j = koff ? (koff - 1u) >> 5 : 0u;
     uint32_t rec = node + j, o = koff - 32u * j;  // (the dictionary of an index with stretch records names records)
-    if (nodes == 0) first_rec = rec;
+    if (first_seed) first_rec = rec;
     else if (ix.srec_base[rec] != ix.srec_base[first_rec]) acc = 0;  // a seed in another component: no row in common
+    first_seed = false;
     uint32_t kpos = kmer_pos + KMER;
     cov += KMER;
-    uint32_t seen = 0, tneed = NO_TENT, t_cov = 0;
+    uint32_t seen = 0, tneed = NO_TENT, t_cov = 0, t_pos = 0;
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
     bool load = true, push = true;
     status = -1;
@@ -1145,18 +1172,18 @@ __device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t 
             const uint32_t k = c - 1u - (bit >> 1);  // bases in front of the first differing one
             if (tent) {
               // a second difference inside the 32 bases: back to the first one, general search (walk(): the same)
-              kpos = (uint32_t)(pend & 0xFFFFu) - 1u;
+              kpos = t_pos;
               cov = t_cov;
-              pend >>= 16;
               adv = 0;
               status = 2;
-            } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos && (pend >> 48) == 0) {
+            } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos &&
+                       !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + kpos + k + 1u, KMER - 1u))) {
               // the rest of this very stretch agrees: go on tentatively from here (walk(): "on")
-              t_cov = cov + k;  // (where the walk stands if the short cut does not work out: at the differing base)
+              t_pos = kpos + k;  // (where the walk stands if the short cut does not work out: at the differing base)
+              t_cov = cov + k;
               mm += 1;
               cov -= 1;  // (the differing base itself is not covered)
               tneed = 32u - (c - 1u - k) + c;
-              pend = (pend << 16) | (uint64_t)(kpos + k + 1u);
             } else {
               prem = true;
               mm += 1;
@@ -1206,9 +1233,8 @@ __device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t 
             push = !tent;
           } else if (tent) {
             // the read leaves the graph inside the tentative stretch: back to the differing base, general search
-            kpos = (uint32_t)(pend & 0xFFFFu) - 1u;
+            kpos = t_pos;
             cov = t_cov;
-            pend >>= 16;
             status = 2;
           } else {
             status = kpos > last_kmer_pos ? 0 : 2;  // no such edge: the end, or a new seed is needed
@@ -1224,13 +1250,6 @@ __device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t 
       break;
     }
   }
-  // the flank tests owed for the substitutions stepped over: the k-mer at p must be absent, i.e. the 29 bases behind p
-  // (the graph's, they agreed) must have one left flank only
-  for (; status == 0 && pend; pend >>= 16) {
-    const uint32_t p1 = (uint32_t)(pend & 0xFFFFu);
-    if (mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + p1, KMER - 1u))) status = 1;
-  }
-  if (status != 0) return 2;
   ln.nodes += nodes;
   ln.probes += 2u * commits;
   if (ln.want_counters) ln.entries += entries;
@@ -1243,7 +1262,7 @@ __device__ __forceinline__ int walk_fast(const DevIndex &ix, Lane &ln, uint32_t 
   ln.all_mask = true;
   coverage = cov;
   mismatches = mm;
-  return 1;
+  return true;
 }
 
 // general form of nodes_to_eq_class (some visited class spans 64 rows or more): smallest class first,
@@ -1449,12 +1468,18 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 // out-of-line call alone costs the walk registers around it.
 // (the instantiation for indexes with wide classes carries the register window and the general intersection: it gets
 // 80 registers, i.e. 6 waves per SIMD, instead of spilling at 64)
-// MODE (round 4): 0 = every read through walk(), as before.  1 = the FAST launch: seeded mates go through walk_fast; a read
-// either of whose mates it does not handle is put on the call's redo list (cb.redo, cb.redo_ctl[0] = how many) with
-// nothing of it counted, and gets its results from the launch behind this one.  2 = that launch: MODE 0 over the reads of
-// the redo list (their number and the tile counter live in cb.redo_ctl; results are stored by read id).
+// MODE (round 4): 0 = every mate through walk() over the 64-byte unitig records; 1 = through walk_fast over the index's
+// stretch records (indexes without wide classes that carry them).
 template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
-__global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES) / ((COUNTERS && MODE == 1) ? 2 : 1)) void k_align(DevIndex ix, nimble_align_params p,
+// (residency: 8 waves per SIMD for the general walk -- 7 and 6 measured slower, round 2 --, 6 for indexes with wide classes (the
+// register window), 7 for the fast walk: at 64 registers it spills inside the tile loop, 72 hold it: bench recipe 1.149 -> 1.115 ms,
+// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; the counters variant of the fast walk, never timed, gets half of that:
+// profiles/r04_experiments.txt 8)
+#ifndef NIMBLE_FAST_WAVES
+#define NIMBLE_FAST_WAVES 7
+#endif
+__global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : NIMBLE_FAST_WAVES)
+                                                    : (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES)) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   static_assert(!(WIDE && MODE == 1), "the fast walk is for indexes whose classes all have the mask form");
   constexpr int want_counters = COUNTERS ? 1 : 0;
@@ -1493,28 +1518,14 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
                   : nullptr;
   ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
-  const uint64_t n = MODE == 2 ? cb.redo_ctl[0] : cb.n;
-  if (MODE == 2 && n == 0) return;  // (nothing was left to redo: the usual case for reads without differences)
+  const uint64_t n = cb.n;
   const uint64_t n_tiles = (n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  unsigned long long *const tile_counter =
-      (unsigned long long *)cb.tile_ctr + (MODE == 2 ? (size_t)TILE_COUNTERS * (TILE_COUNTER_STRIDE / 8) : 0);
-  // read id of the i-th read of this launch
-  auto rid = [&](uint64_t i) -> uint64_t { return MODE == 2 ? (uint64_t)cb.redo[i] : i; };
+  unsigned long long *const tile_counter = (unsigned long long *)cb.tile_ctr;
 
   // small block-shared arrays behind the columns in the dynamic region (extern base stays 16-byte aligned)
   uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) +
                                                LDS_COLS * ALIGN_BLOCK);
   unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
-  // (fast launch) the block's queue of reads for the redo list: the region of the colour list, which an index without wide
-  // classes never uses (LDS_COLS * ALIGN_BLOCK words), its fill and the global position of a hand-over beside the tile slot.
-  // One global atomic per REDO_FLUSH queued reads: an atomic per wave and tile on the list's one counter was 150 k
-  // same-address atomics per 10 M reads -- 1.7 ms of one L2 channel (same-address atomics run at ~90 M/s).
-  uint32_t *const s_redo = reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK);
-  uint32_t &s_rcount = *reinterpret_cast<uint32_t *>(extra + 8);  // queued | handed over in this round << 16
-  uint32_t &s_rbase = *reinterpret_cast<uint32_t *>(extra + 12);
-  constexpr uint32_t REDO_FLUSH = ALIGN_BLOCK;
-  static_assert(MODE != 1 || LDS_COLS * ALIGN_BLOCK >= 2 * REDO_FLUSH, "the queue holds a hand-over's worth plus one tile's bails");
-  if (MODE == 1 && tid == 0) s_rcount = 0;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
   uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
   uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
@@ -1527,25 +1538,32 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
   // range is used up, from the next one, and it asks for its next tile while it works on the current one (the atomic's
   // round trip used to stand between two barriers of every tile).
   const unsigned long long tiles_per_counter = (n_tiles + TILE_COUNTERS - 1) / TILE_COUNTERS;
-  unsigned long long next_tile = ~0ULL;     // (thread 0) the tile fetched ahead; >= n_tiles: none is left
-  uint32_t my_counter = blockIdx.x % TILE_COUNTERS, counters_tried = 0;
-  auto fetch_tile = [&]() {
-    next_tile = n_tiles;
+  // (thread 0's state of this lives in LDS beside the tile slot, not in registers every lane would carry through the walk:
+  // the tile fetched ahead in the low 48 bits -- all ones: none is left --, the counter drawn from and how many were found
+  // used up above them)
+  unsigned long long &s_next = *reinterpret_cast<unsigned long long *>(extra + 8);
+  constexpr unsigned long long NO_TILE = (1ULL << 48) - 1ULL;
+  auto fetch_tile = [&](bool first_call) {
+    uint32_t my_counter = first_call ? blockIdx.x % TILE_COUNTERS : (uint32_t)(s_next >> 48) & 0xFFu;
+    uint32_t counters_tried = first_call ? 0u : (uint32_t)(s_next >> 56);
+    unsigned long long got = NO_TILE;
     while (counters_tried < TILE_COUNTERS) {
       const unsigned long long first = (unsigned long long)my_counter * tiles_per_counter;
       if (first < n_tiles) {  // (a small launch leaves most ranges empty: nothing to ask them)
         const unsigned long long t = atomicAdd(tile_counter + (size_t)my_counter * (TILE_COUNTER_STRIDE / 8), 1ULL);
         if (t < tiles_per_counter && first + t < n_tiles) {
-          next_tile = first + t;
-          return;
+          got = first + t;
+          break;
         }
       }
       my_counter = my_counter + 1 == TILE_COUNTERS ? 0u : my_counter + 1;  // used up: on to the neighbour's range
       ++counters_tried;
     }
+    s_next = got | ((unsigned long long)my_counter << 48) | ((unsigned long long)counters_tried << 56);
   };
+  static_assert(TILE_COUNTERS <= 128, "the counter's number and the count of used-up ones share 16 bits of a word");
 #ifndef NIMBLE_STATIC_TILES
-  if (tid == 0) fetch_tile();
+  if (tid == 0) fetch_tile(true);
 #endif
   PROF_DECL
   for (;;) {
@@ -1558,10 +1576,9 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
     // on a permutation of the tile): written out here, every wave stores 64 consecutive reads per instruction -- whole
     // lines instead of 64 scattered words per store that leave L2 as partial lines.
     if (prev_tile != ~0ULL) {
-      const uint64_t rp_i = prev_tile * ALIGN_BLOCK + tid;
+      const uint64_t rp = prev_tile * ALIGN_BLOCK + tid;
 #ifndef NIMBLE_SKEL_NOSTORE  // (experiments: the skeleton without its result stores)
-      if (rp_i < n) {
-        const uint64_t rp = rid(rp_i);
+      if (rp < n) {
         const uint64_t rs = col[nm * ALIGN_BLOCK];
 #pragma unroll
         for (int m = 0; m < nm; ++m) {
@@ -1580,34 +1597,22 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
       s_tile = prev_tile == ~0ULL ? (unsigned long long)blockIdx.x : prev_tile + gridDim.x;
       (void)tile_counter;
 #else
-      s_tile = next_tile;
+      s_tile = (s_next & NO_TILE) == NO_TILE ? n_tiles : (s_next & NO_TILE);
 #endif
-      if (MODE == 1) {
-        // hand REDO_FLUSH queued reads over to the list -- all of them when this block is about to leave
-        const uint32_t q = s_rcount & 0xFFFFu, give = s_tile >= n_tiles ? q : (q >= REDO_FLUSH ? REDO_FLUSH : 0u);
-        if (give) s_rbase = (uint32_t)atomicAdd((unsigned long long *)&cb.redo_ctl[0], (unsigned long long)give);
-        s_rcount = (q - give) | (give << 16);  // (the entries handed over are the queue's last `give`)
-      }
     }
     __syncthreads();
     const uint64_t tile = s_tile;
-    if (MODE == 1) {
-      const uint32_t left = s_rcount & 0xFFFFu, give = s_rcount >> 16;
-      for (uint32_t k = tid; k < give; k += ALIGN_BLOCK) cb.redo[(uint64_t)s_rbase + k] = s_redo[left + k];
-      // (the next tile's bails are appended behind `left` only after the partition's barriers below)
-    }
     PROF(0)
     if (tile >= n_tiles) break;
 #ifndef NIMBLE_STATIC_TILES
-    if (tid == 0) fetch_tile();  // (consumed at the head of the next round)
+    if (tid == 0) fetch_tile(false);  // (consumed at the head of the next round)
 #endif
     prev_tile = tile;
     // ---- own slot: key into LDS column tid, first direct probe of mate 0
-    const uint64_t i_own = tile * ALIGN_BLOCK + tid;
-    const uint64_t r_own = i_own < n ? rid(i_own) : 0;
+    const uint64_t r_own = tile * ALIGN_BLOCK + tid;
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
     uint64_t seedv = ~0ULL;
-    if (i_own < n) {
+    if (r_own < n) {
       // Everything the tile needs from memory is asked for at once: the key words do not wait for the lengths (what lies
       // behind a key is masked when the lengths are there).  A tile is a chain of dependent round trips -- tile index,
       // lengths, key words, first probe, the walk's records -- and a block does nothing else meanwhile: a launch over reads
@@ -1636,7 +1641,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
       if (pre0 == R_TODO && l0 >= KMER) {
         uint32_t nd = 0, of = 0;
         ln.rd = col;
-        if (probe_direct(ix, ln, 0u, 0u, nd, of, MODE != 1)) {  // (the fast launch counts a read's probes when the read is done)
+        if (probe_direct(ix, ln, 0u, 0u, nd, of, MODE != 1)) {  // (walk_fast counts the tile's probe of a mate itself)
           kind = 1;
           seedv = u64of(of, nd);
         } else {
@@ -1674,9 +1679,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
     }
     PROF(2)
     const uint32_t slot = s_perm[tid];
-    const uint64_t r_i = tile * ALIGN_BLOCK + slot;
-    const bool active = r_i < n;
-    const uint64_t r = active ? rid(r_i) : 0;
+    const uint64_t r = tile * ALIGN_BLOCK + slot;
+    const bool active = r < n;
     ln.rd = lds64 + slot;
     const uint64_t pre_seed = s_seed[slot];
     uint32_t L[2] = {0, 0};   // aligned bases per mate
@@ -1689,10 +1693,6 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
       }
     }
     bool any_walk = false;
-    // (fast launch) a read that bails leaves no trace in the work counters: they are taken back to where the read began
-    bool bail = false, pre_counted = false;
-    const uint32_t probes_r0 = ln.probes, nodes_r0 = ln.nodes;
-    const uint64_t entries_r0 = ln.entries;
     uint64_t res_v[2] = {0, 0}, res_r = 0;  // (staged results: score | mismatches << 16 | class << 32 per mate; reasons)
     for (int m = 0; m < nm; ++m) {
       uint32_t reason = NIMBLE_R_NONE, score = 0, mm = 0, cls = CLS_NONE;
@@ -1706,9 +1706,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
         uint32_t pre = rd_pre(cb, m, r);
         if (pre != R_TODO) {
           reason = pre;
-          if (m == 0) pre_counted = true;
-        } else if (MODE == 1 && bail) {
-          // (mate 0 put the read on the redo list already)
+          if (m == 0) c_pre++;
         } else {
           uint32_t cov = 0, mis = 0;
           const uint32_t pre_state = m == 0 ? (pre_seed != ~0ULL ? 2u : 1u) : 0u;
@@ -1716,17 +1714,13 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
           bool some;
           if (MODE == 1) {
             const uint32_t base0 = m ? mate1_at : 0u;
-            const int w = p.num_mismatches == 0 ? walk_fast<true>(ix, ln, base0, L[m], 0u, pre_state, pre_seed, cov, mis)
-                                                : walk_fast<false>(ix, ln, base0, L[m], p.num_mismatches, pre_state, pre_seed, cov, mis);
-            some = w == 1;
-            bail = w == 2;
+            some = p.num_mismatches == 0 ? walk_fast<true>(ix, ln, base0, L[m], 0u, pre_state, pre_seed, cov, mis)
+                                         : walk_fast<false>(ix, ln, base0, L[m], p.num_mismatches, pre_state, pre_seed, cov, mis);
           } else {
             some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed PROF_PASS);
           }
           PROF(3)
-          if (MODE == 1 && bail) {
-            // nothing of this read is kept
-          } else if (!some) {
+          if (!some) {
             reason = NIMBLE_R_NO_MATCH;
           } else {
             any_walk = true;
@@ -1837,26 +1831,6 @@ __global__ __launch_bounds__(ALIGN_BLOCK, (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 :
       c[nm * ALIGN_BLOCK] = res_r;
     }
 #endif
-    if (MODE == 1) {
-      // the reads this launch did not handle go on the redo list (one atomic per wave); what they left in the lane's work
-      // counters is taken back, and whatever was staged for them above is overwritten by the launch that redoes them
-      const uint64_t bm = __ballot(active && bail);
-      if (bm) {  // into the block's queue (an LDS atomic per wave); handed over to the list at the head of a later tile
-        const uint32_t lane = tid & 63u, leader = (uint32_t)__ffsll((long long)bm) - 1u;
-        uint32_t at = 0;
-        if (lane == leader) at = atomicAdd(&s_rcount, (uint32_t)__popcll(bm)) & 0xFFFFu;
-        at = __shfl(at, (int)leader, 64);
-        if (active && bail) s_redo[at + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = (uint32_t)r;
-      }
-      if (bail) {
-        ln.probes = probes_r0;
-        ln.nodes = nodes_r0;
-        ln.entries = entries_r0;
-        pre_counted = false;
-        any_walk = false;
-      }
-    }
-    if (pre_counted) c_pre++;
     if (any_walk) c_seeded++;
   }
 #if NIMBLE_PROFILE_SECTIONS
@@ -2592,12 +2566,11 @@ static int resident_blocks(const void *fn, size_t lds, int *cus_out) {
   return per_cu;
 }
 
-// mode: 0 = the classic launch, 1 = the fast launch (indexes without wide classes only), 2 = the redo launch behind it
+// mode: 0 = the general walk, 1 = the fast walk (indexes with stretch records)
 static const void *align_kernel(bool paired, bool counters, bool wide, int mode) {
-#define NIMBLE_PICK(P, C)                                                                                        \
-  (mode == 1 ? (const void *)k_align<P, C, false, 1>                                                              \
-             : mode == 2 ? (const void *)k_align<P, C, false, 2>                                                  \
-                         : (wide ? (const void *)k_align<P, C, true, 0> : (const void *)k_align<P, C, false, 0>))
+#define NIMBLE_PICK(P, C)                                    \
+  (mode == 1 ? (const void *)k_align<P, C, false, 1>          \
+             : (wide ? (const void *)k_align<P, C, true, 0> : (const void *)k_align<P, C, false, 0>))
   return paired ? (counters ? NIMBLE_PICK(true, true) : NIMBLE_PICK(true, false))
                 : (counters ? NIMBLE_PICK(false, true) : NIMBLE_PICK(false, false));
 #undef NIMBLE_PICK
@@ -2647,37 +2620,18 @@ static size_t align_lds(const DevIndex &ix, const CallBuffers &cb) {
          (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
 }
 
-// Indexes with stretch records take the FAST launch (walk_fast) followed by the launch that redoes, through walk(), the
-// reads the fast one put on the call's redo list -- a few per cent of them.  NIMBLE_FAST_ALIGN=0, an index with wide
-// classes, or a context without a redo list: the classic launch.  Returns true when the redo launch is still owed
-// (with_redo = false: the caller places it, e.g. on the side stream beside the next call's pack).
-bool launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                  int want_counters, int grid_pct, int n_cus, bool with_redo) {
-  if (cb.n == 0) return false;
-  const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  const bool wide = ix.all_local == 0;
-  const size_t lds = align_lds(ix, cb);
-  static const bool fast_on = !(getenv("NIMBLE_FAST_ALIGN") && atoi(getenv("NIMBLE_FAST_ALIGN")) == 0);
-  // (both launches' tile counters and, right behind them, the redo list's control words: one fill)
-  (void)hipMemsetAsync(cb.tile_ctr, 0, 2 * (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE + 4 * sizeof(uint64_t), s);
-  if (fast_on && !wide && ix.srec && ix.mleft && cb.redo && cb.redo_ctl) {
-    launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 1), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
-    if (!with_redo) return true;
-    launch_align_redo(s, ix, p, cb, want_counters, grid_pct, n_cus);
-    return false;
-  }
-  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, 0), lds, ix, p, cb, tiles, grid_pct, n_cus, 0);
-  return false;
-}
-
-// the launch behind the fast one: walk() over the reads of the redo list.  How many those are is known on the device only:
-// a grid for a sixteenth of the reads; the blocks take tiles of the list until it is empty, most of them none.
-void launch_align_redo(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
-                       int want_counters, int grid_pct, int n_cus) {
+// Indexes with stretch records (no wide classes, components that fit a 64-row window, a "several left flanks" set) take the
+// fast walk (walk_fast); NIMBLE_FAST_ALIGN=0 or any other index: the general one.
+void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &p, const CallBuffers &cb,
+                  int want_counters, int grid_pct, int n_cus) {
   if (cb.n == 0) return;
   const uint64_t tiles = (cb.n + ALIGN_BLOCK - 1) / ALIGN_BLOCK;
-  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, false, 2), align_lds(ix, cb), ix, p, cb, tiles, grid_pct,
-                      n_cus, tiles / 16 + 1);
+  const bool wide = ix.all_local == 0;
+  static const bool fast_on = !(getenv("NIMBLE_FAST_ALIGN") && atoi(getenv("NIMBLE_FAST_ALIGN")) == 0);
+  const bool fast = fast_on && !wide && ix.srec && ix.mleft;
+  (void)hipMemsetAsync(cb.tile_ctr, 0, (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE, s);  // (the launch's tile counters)
+  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, fast ? 1 : 0), align_lds(ix, cb), ix, p, cb, tiles,
+                      grid_pct, n_cus, 0);
 }
 
 void launch_intern_claim(hipStream_t s, const DevIndex &ix, const CallBuffers &cb, int round) {
