@@ -1077,7 +1077,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
   uint32_t nodes = 0, commits = 0;
   uint64_t entries = 0;
   uint64_t acc = ~0ULL;
-  uint32_t min_len = 0xFFFFFFFFu, min_col = 0, first_rec = 0;
+  uint32_t min_len = 0xFFFFFFFFu, min_col = 0, rec = 0;
   int status;  // -1 walking, 0 done, 2 the next seed has to be searched from kpos
   if (kmer_pos >= (uint32_t)(0.2 * (double)L)) {
     // LEFT EXTENSION behind a late first seed, as in walk(): the read's bases in front of the seed against the unitig, and
@@ -1113,13 +1113,15 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
     // the seed's k-mer is the unitig's k-mer at offset koff: what is compared next is the unitig's base 30 + koff, i.e.
     // base o of its stretch j (o = 32 <=> that stretch is used up; koff = 0: the head of the unitig)
     const uint32_t j = koff ? (koff - 1u) >> 5 : 0u;
-    uint32_t rec = node + j, o = koff - 32u * j;  // (the dictionary of an index with stretch records names records)
-    if (first_seed) first_rec = rec;
-    else if (ix.srec_base[rec] != ix.srec_base[first_rec]) acc = 0;  // a seed in another component: no row in common
+    const uint32_t seed_rec = node + j;  // (the dictionary of an index with stretch records names records)
+    // (a seed in another component than the walk so far -- `rec` still is a record of that -- has no row in common with it)
+    if (!first_seed && ix.srec_base[seed_rec] != ix.srec_base[rec]) acc = 0;
     first_seed = false;
+    rec = seed_rec;
+    uint32_t o = koff - 32u * j;
     uint32_t kpos = kmer_pos + KMER;
     cov += KMER;
-    uint32_t seen = 0, tneed = NO_TENT, t_cov = 0, t_pos = 0;
+    uint32_t seen = 0, tneed = NO_TENT, t_pos = 0;
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
     bool load = true, push = true;
     status = -1;
@@ -1172,15 +1174,15 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
             const uint32_t k = c - 1u - (bit >> 1);  // bases in front of the first differing one
             if (tent) {
               // a second difference inside the 32 bases: back to the first one, general search (walk(): the same)
+              // (coverage at the differing base: read position and coverage move together, the tentative stretch is one behind)
+              cov = t_pos - (kpos - cov - 1u);
               kpos = t_pos;
-              cov = t_cov;
               adv = 0;
               status = 2;
             } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos &&
                        !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + kpos + k + 1u, KMER - 1u))) {
               // the rest of this very stretch agrees: go on tentatively from here (walk(): "on")
               t_pos = kpos + k;  // (where the walk stands if the short cut does not work out: at the differing base)
-              t_cov = cov + k;
               mm += 1;
               cov -= 1;  // (the differing base itself is not covered)
               tneed = 32u - (c - 1u - k) + c;
@@ -1233,8 +1235,8 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
             push = !tent;
           } else if (tent) {
             // the read leaves the graph inside the tentative stretch: back to the differing base, general search
+            cov = t_pos - (kpos - cov - 1u);
             kpos = t_pos;
-            cov = t_cov;
             status = 2;
           } else {
             status = kpos > last_kmer_pos ? 0 : 2;  // no such edge: the end, or a new seed is needed
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
   if (ln.want_counters) ln.entries += entries;
   ln.walk_nodes = nodes;
   ln.acc = acc;
-  ln.last_rec = first_rec;  // (srec_base[first_rec] is the first visited unitig's first row: the walk's fbase, if anybody asks)
+  ln.last_rec = rec;  // (srec_base of any record of the walk is its component's first row: the walk's fbase, if anybody asks)
   ln.fbase = 0;
   ln.min_len = min_len;
   ln.min_col = min_col;
@@ -1473,12 +1475,13 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
 // (residency: 8 waves per SIMD for the general walk -- 7 and 6 measured slower, round 2 --, 6 for indexes with wide classes (the
 // register window), 7 for the fast walk: at 64 registers it spills inside the tile loop, 72 hold it: bench recipe 1.149 -> 1.115 ms,
-// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; the counters variant of the fast walk, never timed, gets half of that:
+// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; paired calls carry two mates' state: 6 waves, configs[3] 2.57 -> 2.50 ms;
+// the counters variant of the fast walk, never timed, gets half of that:
 // profiles/r04_experiments.txt 8)
 #ifndef NIMBLE_FAST_WAVES
 #define NIMBLE_FAST_WAVES 7
 #endif
-__global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : NIMBLE_FAST_WAVES)
+__global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : (PAIRED ? NIMBLE_FAST_WAVES - 1 : NIMBLE_FAST_WAVES))
                                                     : (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES)) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   static_assert(!(WIDE && MODE == 1), "the fast walk is for indexes whose classes all have the mask form");
