@@ -104,6 +104,10 @@ int nimble_class_pool_read(const nimble_index *, uint32_t pool_off, uint32_t cou
 /* Host-only diagnostic: builds the flat index exactly as nimble_index_build does but uploads nothing.
  * stats[0..4] as nimble_index_stats.  Lets CPU-only tests check the index builder. */
 int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t stats[5]);
+/* Host-only as well: builds the flat index and checks its stretch records (what the fast walk of k_align reads) against the
+ * unitig records they were cut from; *n_records = how many there are (0: this index takes the general walk).  NIMBLE_OK, or
+ * NIMBLE_E_INTERNAL with what is wrong first. */
+int nimble_flat_index_selfcheck(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t *n_records);
 
 /* ---- context ---- */
 /* stream: a hipStream_t (as void*) to launch on, or NULL for the context's own stream. */

@@ -87,7 +87,7 @@ HIP_SYMBOLS = [
     "nimble_abi_version", "nimble_last_error", "nimble_device_count", "nimble_index_build", "nimble_index_free",
     "nimble_index_stats", "nimble_class_get", "nimble_ctx_create", "nimble_ctx_free", "nimble_ctx_synchronize",
     "nimble_call", "nimble_histogram", "nimble_histogram_dense_se", "nimble_read_records", "nimble_call_counters",
-    "nimble_call_timing", "nimble_flat_index_stats", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
+    "nimble_call_timing", "nimble_flat_index_stats", "nimble_flat_index_selfcheck", "nimble_ctx_set_option", "nimble_key_words", "nimble_pack",
     "nimble_call_packed", "nimble_call_words", "nimble_ctx_stream", "nimble_stream_begin", "nimble_stream_append", "nimble_stream_append_packed", "nimble_stream_end",
     "nimble_pinned_alloc", "nimble_pinned_free", "nimble_call_ex", "nimble_histogram_seg", "nimble_read_align_len",
     "nimble_route_records", "nimble_unpack_records", "nimble_pinned_register", "nimble_pinned_unregister",
@@ -115,6 +115,7 @@ def hip_lib():
         L.nimble_index_free.argtypes = [vp]
         L.nimble_index_free.restype = None
         L.nimble_flat_index_stats.argtypes = [vp, vp, u32, C.POINTER(u64)]
+        L.nimble_flat_index_selfcheck.argtypes = [vp, vp, u32, C.POINTER(u64)]
         L.nimble_index_stats.argtypes = [vp, C.POINTER(u64)]
         L.nimble_class_get.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
         L.nimble_ctx_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -236,6 +237,15 @@ def flat_index_stats(sequences):
     s = (C.c_uint64 * 5)()
     _check(hip_lib().nimble_flat_index_stats(buf.ctypes.data, off.ctypes.data, len(sequences), s))
     return dict(kmers=s[0], nodes=s[1], classes=s[2], unitig_bases=s[3], class_entries=s[4])
+
+
+def flat_index_selfcheck(sequences):
+    """Host-only: builds the flat index and checks its stretch records against the unitig records; returns how many records
+    there are (0: the index takes the general walk).  Raises NimbleError with what is wrong."""
+    buf, off = pack_reads(sequences)
+    n = C.c_uint64()
+    _check(hip_lib().nimble_flat_index_selfcheck(buf.ctypes.data, off.ctypes.data, len(sequences), C.byref(n)))
+    return int(n.value)
 
 
 class Index:

@@ -828,6 +828,22 @@ int nimble_index_build(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_
   }
 }
 
+int nimble_flat_index_selfcheck(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t *n_records) {
+  if ((!seqs && n_seqs) || !seq_off) return fail(NIMBLE_E_INVALID, "nimble_flat_index_selfcheck: NULL argument");
+  try {
+    FlatIndex fi;
+    build_flat_index(seqs, seq_off, n_seqs, fi);
+    if (n_records) *n_records = fi.srec.size() / 8;
+    const std::string what = check_stretch_records(fi);
+    if (!what.empty()) return fail(NIMBLE_E_INTERNAL, "stretch records: " + what);
+  } catch (const std::exception &e) {
+    return fail(NIMBLE_E_INTERNAL, e.what());
+  } catch (...) {
+    return fail(NIMBLE_E_INTERNAL, "nimble_flat_index_selfcheck: unknown failure");
+  }
+  return NIMBLE_OK;
+}
+
 int nimble_flat_index_stats(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n_seqs, uint64_t s[5]) {
   if ((!seqs && n_seqs) || !seq_off || !s) return fail(NIMBLE_E_INVALID, "nimble_flat_index_stats: NULL argument");
   try {

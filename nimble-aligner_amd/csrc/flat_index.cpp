@@ -588,4 +588,52 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   }
 }
 
+std::string check_stretch_records(const FlatIndex &fi) {
+  if (fi.srec.empty()) return fi.uniform_windows && fi.n_nodes ? "an index with uniform windows has no stretch records" : "";
+  const size_t n_rec = fi.srec.size() / 8;
+  if (fi.srec_first.size() != fi.n_nodes || fi.srec_base.size() != n_rec) return "srec_first / srec_base have the wrong size";
+  auto base_at = [&](uint64_t pos) { return (uint32_t)((fi.unitig[pos >> 5] >> (62 - 2 * (pos & 31))) & 3ULL); };
+  std::vector<uint8_t> owned(n_rec, 0);
+  for (size_t nd = 0; nd < fi.n_nodes; ++nd) {
+    const uint32_t *nr = &fi.node_rec[nd * 16];
+    const uint32_t len = nr[0] & 0xFFFFFFu, rext = (nr[0] >> 28) & 0xFu, inf = len - KMER;
+    const uint32_t want_rec = std::max<uint32_t>(1u, (inf + 31u) / 32u), first = fi.srec_first[nd];
+    if ((size_t)first + want_rec > n_rec) return "a unitig's records lie beyond the array";
+    uint32_t covered = 0;
+    for (uint32_t j = 0; j < want_rec; ++j) {
+      const uint32_t *r = &fi.srec[((size_t)first + j) * 8];
+      if (owned[first + j]++) return "two unitigs share a record";
+      const uint32_t nb = r[0] & 63u;
+      if (nb > 32u || (j + 1 < want_rec && nb != 32u)) return "a stretch that is not the unitig's last holds fewer than 32 bases";
+      if (((r[0] >> 8) & 0xFu) != rext) return "a record's extension bits differ from its unitig's";
+      if (((r[0] & SREC_LAST) != 0) != (j + 1 == want_rec)) return "SREC_LAST is not on the unitig's last stretch only";
+      if (((r[0] >> 16) & 0x7Fu) != (nr[3] & 0x7Fu) || !(nr[3] & CLS_MASK_FLAG)) return "class length / form differs";
+      if (r[1] != nr[1]) return "colour differs";
+      if (r[4] != nr[5] || r[5] != nr[6]) return "class mask differs";
+      if (fi.srec_base[first + j] != nr[4]) return "srec_base is not the component's first row";
+      const uint64_t bases = (uint64_t)r[2] | ((uint64_t)r[3] << 32);
+      for (uint32_t b = 0; b < nb; ++b)
+        if (((bases >> (62 - 2 * b)) & 3ULL) != base_at((uint64_t)nr[2] + KMER + covered + b)) return "a stretch's bases differ from the unitig's";
+      if (nb < 32u && (bases << (2 * nb)) != 0 && nb != 0) return "bits behind a stretch's last base";
+      covered += nb;
+      if (j + 1 == want_rec) {
+        const uint32_t ways = (uint32_t)__builtin_popcount(rext);
+        if (((r[0] & SREC_MANY) != 0) != (ways > 2)) return "SREC_MANY does not mark the forks with more than two ways out";
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < 4; ++b)
+          if (rext & (1u << b)) {
+            const uint32_t target = fi.srec_first[nr[8 + b]];
+            const uint32_t have = ways > 2 ? fi.srec_many[(size_t)r[6] * 4 + b] : r[6 + k];
+            if (have != target) return "a right neighbour's record is wrong";
+            ++k;
+          }
+      }
+    }
+    if (covered != inf) return "a unitig's stretches do not add up to its bases behind the first k-mer";
+  }
+  for (size_t i = 0; i < n_rec; ++i)
+    if (!owned[i]) return "a record belongs to no unitig";
+  return "";
+}
+
 }  // namespace nimble

@@ -207,5 +207,10 @@ struct FlatIndex {
 
 // seqs: concatenated ASCII, off[n+1].  Throws std::runtime_error on inconsistency.
 void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs, FlatIndex &out);
+// The stretch records against the unitig records they were cut from: every unitig's records spell its bases from base 30 on
+// (against the packed unitig buffer), carry its class mask, length and colour, end in its right neighbours' first records
+// (forks with more than two in srec_many), and srec_first / srec_base name what they should.  Returns an empty string, or what
+// is wrong first.  (CPU test of the builder: tests/test_host_cpu.py.)
+std::string check_stretch_records(const FlatIndex &fi);
 
 }  // namespace nimble

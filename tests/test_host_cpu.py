@@ -490,3 +490,39 @@ def test_offsets_argument_refuses_byte_arrays():
         lib.score_call(a, a, n=2, fixed_len=150)
     with pytest.raises(TypeError, match="64-bit"):
         lib.score_call_begin(0, a, a, n=2, fixed_len=150)
+
+
+# ---------------- stretch records of the fast walk (round 4) ----------------
+def test_stretch_records_spell_the_unitigs():
+    """The index's stretch records (what walk_fast of k_align gathers: csrc/flat_index.h FlatIndex::srec) against the unitig
+    records they were cut from -- bases, class, extension bits, neighbours, forks with more than two ways out -- on the
+    reference's fixture libraries, the synthetic bench library, and libraries with long unitigs, repeats and 3-4 way forks."""
+    import json as _json
+    rng = np.random.default_rng(5)
+    cases = []
+    for lib in ("basic.json", "basic-rev.json", "mismatch.json", "strandedness.json"):
+        obj = _json.load(open(lib_path(lib)))
+        names, seqs = obj[1]["columns"][1], obj[1]["columns"][3]
+        cases.append(synth.expand_rows(names, seqs)[1])
+    names, seqs = synth.make_library(120)
+    cases.append(synth.expand_rows(names, seqs)[1])
+    # long unitigs (unique genes of 3 kb: many continuation records) beside families with 3 and 4 alleles differing at ONE site
+    # (forks with three and four ways out), a homopolymer run and a tandem repeat
+    genes = ["".join(rng.choice(list("ACGT"), size=3000)) for _ in range(3)]
+    root = "".join(rng.choice(list("ACGT"), size=400))
+    fork = [root[:200] + b + root[201:] for b in "ACGT"]
+    odd = ["A" * 90 + "".join(rng.choice(list("ACGT"), size=60)), ("ACGTTGCA" * 20)[:150] + "".join(rng.choice(list("ACGT"), size=50))]
+    cases.append(genes + fork + fork[:3] + odd)
+    for rows in cases:
+        n_rec = nim.flat_index_selfcheck(rows)
+        st = nim.flat_index_stats(rows)
+        assert n_rec >= st["nodes"] > 0          # a record or more per unitig
+    # an index whose classes do not fit the 64-row mask form takes the general walk: no stretch records
+    fam = ["".join(rng.choice(list("ACGT"), size=300))]
+    wide = []
+    for a in range(80):
+        s = list(fam[0])
+        for p_ in np.nonzero(rng.random(len(s)) < 0.01)[0]:
+            s[p_] = "ACGT"[("ACGT".index(s[p_]) + 1) % 4]
+        wide.append("".join(s))
+    assert nim.flat_index_selfcheck(wide) == 0
