@@ -466,7 +466,12 @@ template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __buil
 #define NIMBLE_GATHER_POLICY 0
 #endif
 __device__ __forceinline__ uint4 ld_gather(const uint4 *p) {
-#if NIMBLE_GATHER_POLICY == 0
+#if defined(NIMBLE_GATHER_NT)
+  // (experiments, round 4: the non-temporal hint without a wait behind it -- the compiler's own load, scheduled as any other)
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#elif NIMBLE_GATHER_POLICY == 0
   return *p;
 #else
   uint4 v;
