@@ -50,13 +50,24 @@ constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
 #ifndef NIMBLE_PROFILE_SECTIONS
 #define NIMBLE_PROFILE_SECTIONS 0
 #endif
-#if NIMBLE_PROFILE_SECTIONS
+// NIMBLE_PROFILE_SECTIONS=2: no clocks; WCOUNT(i) counts how often a WAVE executes the block it stands in (whatever the number
+// of active lanes): wave-level trip counts of the divergent paths, to be multiplied with the block's static instruction count.
+#if NIMBLE_PROFILE_SECTIONS == 2
+__device__ unsigned long long g_prof[16];
+#define WCOUNT(i) { if (__lane_id() == (unsigned)__ffsll((unsigned long long)__ballot(1)) - 1u) atomicAdd(&g_prof[i], 1ULL); }
+#define PROF_DECL
+#define PROF(i)
+#define PROF_ARGS
+#define PROF_PASS
+#elif NIMBLE_PROFILE_SECTIONS
+#define WCOUNT(i)
 __device__ unsigned long long g_prof[16];
 #define PROF_DECL unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = clock64();
 #define PROF(i) { const unsigned long long prof_n = clock64(); prof_acc[i] += prof_n - prof_t; prof_t = prof_n; }
 #define PROF_ARGS , unsigned long long *prof_acc, unsigned long long &prof_t
 #define PROF_PASS , prof_acc, prof_t
 #else
+#define WCOUNT(i)
 #define PROF_DECL
 #define PROF(i)
 #define PROF_ARGS
@@ -465,6 +476,14 @@ template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __buil
 #ifndef NIMBLE_GATHER_POLICY
 #define NIMBLE_GATHER_POLICY 0
 #endif
+// a 16-byte load the compiler keeps whole (it takes loads of HIP's uint4 apart into dwords and puts them together again as it
+// likes: a stretch record's two halves became three requests -- 8 + 16 + 8 bytes -- on one line, and the rate of a walk is
+// requests per line, tools/probes/chain.hip)
+__device__ __forceinline__ uint4 ld16(const uint4 *p) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = *reinterpret_cast<const u32x4_t *>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint4 ld_gather(const uint4 *p) {
 #if defined(NIMBLE_GATHER_NT)
   // (experiments, round 4: the non-temporal hint without a wait behind it -- the compiler's own load, scheduled as any other)
@@ -577,6 +596,7 @@ __device__ __forceinline__ uint32_t round_maybe(const DevIndex &ix, const uint64
     if (!((ix.l1[sh >> 5] >> (sh & 31u)) & 1u)) return 0u;
   }
   const uint32_t extra = avail > KMER ? (avail - KMER < span - KMER ? avail - KMER : span - KMER) : 0u;
+  WCOUNT(9)
   const uint64_t tail = extra ? (lds_bits(rd, base0 + kmer_pos + KMER, extra) << (2u * (span - KMER - extra))) : 0ULL;
   const uint4 line = ld_gather(ix.bitmap + round_line(km & ((1ULL << (2u * SCAN_SHARED)) - 1ULL), ix.bm_lines_log2));
   const uint64_t half0 = u64of(line.x, line.y), half1 = u64of(line.z, line.w);
@@ -600,11 +620,13 @@ __device__ __forceinline__ uint32_t round_maybe(const DevIndex &ix, const uint64
 __device__ __forceinline__ bool scan_round(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t &kmer_pos,
                                            uint32_t last_kmer_pos, uint32_t &node, uint32_t &off, bool first = false) {
   uint32_t maybe = round_maybe(ix, ln.rd, base0, kmer_pos, last_kmer_pos, first);
+  WCOUNT(8)
   const uint32_t valid = last_kmer_pos - kmer_pos;
   const uint32_t nvalid = valid / 3u + 1u < SCAN_ROUND ? valid / 3u + 1u : SCAN_ROUND;
   uint32_t examined = nvalid;
   bool found = false;
   while (maybe) {  // candidates in read order (filter false positives or a real seed); usually none
+    WCOUNT(10)
     const uint32_t i = (uint32_t)__ffs((int)maybe) - 1u;
     maybe &= maybe - 1u;
     const uint32_t p = kmer_pos + 3u * i;
@@ -639,6 +661,7 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
                                            uint32_t last_kmer_pos, uint32_t &node, uint32_t &off,
                                            bool skip_direct = false, bool first = false) {
   if (kmer_pos > last_kmer_pos) return false;
+  WCOUNT(7)
   if (!skip_direct) {
     const uint64_t km = lds_bits(ln.rd, base0 + kmer_pos, KMER);
     const uint64_t h = kmer_slot(km, ix.ht_log2);
@@ -651,6 +674,38 @@ __device__ __forceinline__ bool find_match(const DevIndex &ix, Lane &ln, uint32_
       if (v != HT_EMPTY) { off = (uint32_t)v; node = (uint32_t)(v >> 32); return true; }
     }
     kmer_pos += 3;
+  }
+  if (first && ix.l1) {
+    // The first seed of a mate (most of those mates are not from the library at all).  The L2-resident first level clears
+    // 93 % of a foreign read's rounds, but a wave of 64 such reads has a lane that passes it in practically every round, and
+    // the wave then runs the filter-line block (and a candidate probe behind it) round after round for four or five lanes:
+    // six times per wave on the bench reads (profiles/r04_experiments.txt 13).  So: the first level for ALL rounds first
+    // (independent loads, every lane busy), then each lane goes through the rounds that passed -- the wave runs the heavy
+    // block as often as its worst lane has rounds left (two or three times), not once per round.
+    // The reference examines positions one by one up to the first hit: the count follows from the hit's position.
+    const uint32_t start = kmer_pos;
+    bool found = false;
+    for (uint32_t chunk = start; chunk <= last_kmer_pos && !found; chunk += 3u * SCAN_ROUND * 32u) {
+      uint32_t pend = 0, nr = 0;
+      for (uint32_t kp = chunk; kp <= last_kmer_pos && nr < 32u; kp += 3u * SCAN_ROUND, ++nr) {
+        const uint32_t sh = (uint32_t)lds_bits(ln.rd, base0 + kp + (KMER - SCAN_SHARED), SCAN_SHARED);  // (the k-mer's last 12 bases)
+        pend |= ((ix.l1[sh >> 5] >> (sh & 31u)) & 1u) << nr;
+      }
+      const uint32_t counted = ln.probes;
+      while (pend) {
+        const uint32_t r = (uint32_t)__ffs((int)pend) - 1u;
+        pend &= pend - 1u;
+        uint32_t kp = chunk + 3u * SCAN_ROUND * r;
+        if (scan_round(ix, ln, base0, kp, last_kmer_pos, node, off, false)) {
+          found = true;
+          kmer_pos = kp;
+          pend = 0;
+        }
+      }
+      ln.probes = counted;  // (scan_round counted per round; in closed form below)
+    }
+    ln.probes += ((found ? kmer_pos : last_kmer_pos) - start) / 3u + 1u;
+    return found;
   }
   while (kmer_pos <= last_kmer_pos)
     if (scan_round(ix, ln, base0, kmer_pos, last_kmer_pos, node, off, first)) return true;
@@ -1062,9 +1117,10 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
 // walked (the lane's running intersection -- ln.acc / min_* / last_rec -- describes the visited classes).
 template <bool STRICT>
 __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, uint32_t allowed,
-                                          uint32_t pre, uint64_t pre_seed, uint32_t &coverage, uint32_t &mismatches) {
+                                          uint32_t pre, uint64_t pre_seed, uint32_t &coverage, uint32_t &mismatches PROF_ARGS) {
   constexpr uint32_t NO_TENT = 0x40000000u;
   ln.walk_nodes = 0;
+  WCOUNT(1)
   ln.n_cols = 0;
   if (L < KMER) return false;
   const uint64_t *rd = ln.rd;
@@ -1077,6 +1133,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
     kmer_pos = pre == 1u ? 3u : 0u;
     have = find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, pre == 1u, true);
   }
+  PROF(4)
   if (!have) return false;
   uint32_t cov = 0, mm = 0;
   uint32_t nodes = 0, commits = 0;
@@ -1092,6 +1149,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
     uint32_t pnode = ix.srec_node[node];  // (the dictionary names a unitig by its first record)
     uint32_t poff = koff > 0 ? koff - 1 : 0;
     for (;;) {
+      WCOUNT(12)
       const NodeRec nr = load_node(ix, pnode);
       const uint32_t n = last_pos + 1 < poff + 1 ? last_pos + 1 : poff + 1;
       bool prem;
@@ -1131,15 +1189,18 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
     bool load = true, push = true;
     status = -1;
     while (status < 0) {
+      WCOUNT(2)
       if (load) {
+        WCOUNT(3)
         // the record's first half (header, colour, bases: what the compare needs) ahead of the second (class mask,
         // neighbours: needed behind the compare)
-        r0 = ix.srec[(size_t)rec * 2];
-        r1 = ix.srec[(size_t)rec * 2 + 1];
+        r0 = ld16(ix.srec + (size_t)rec * 2);
+        r1 = ld16(ix.srec + (size_t)rec * 2 + 1);
         load = false;
       }
       const uint32_t hdr = r0.x, nb = hdr & 63u;
       if (tneed == 0) {
+        WCOUNT(5)
         // all 32 bases behind the substitution agree: the reference's seed is the k-mer that ends with the last of them,
         // in this unitig -- entered the way a seed is entered (two probes: p missed, p + 3 hit; the 30 bases of the seed
         // count, the 32 compared did not)
@@ -1172,6 +1233,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
         uint64_t m = (x | (x >> 1)) & 0x5555555555555555ULL;
         uint32_t adv = c;
         if (m) {
+          WCOUNT(4)
           const uint32_t cnt = (uint32_t)__popcll(m);
           const bool tent = tneed < NO_TENT / 2;
           if (STRICT || tent) {
@@ -1227,6 +1289,7 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
         } else if (kpos >= L && !tent) {
           status = 0;
         } else {  // the unitig is done: on along the read's next base (the junction base agrees by the edge's label)
+          WCOUNT(6)
           const uint32_t nbase = junction < 4u ? junction : lds_base(rd, base0 + kpos);
           const uint32_t rext = (hdr >> 8) & 0xFu;
           if ((rext >> nbase) & 1u) {
@@ -1249,13 +1312,17 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
         }
       }
     }
+    PROF(5)
     if (status != 2) break;
     // the next seed, searched the way walk() does behind a walk (the scan rounds start at kpos itself)
     kmer_pos = kpos;
+    WCOUNT(11)
     if (!find_match(ix, ln, base0, kmer_pos, last_kmer_pos, node, koff, true, false)) {
       status = 0;
+      PROF(8)
       break;
     }
+    PROF(8)
   }
   ln.nodes += nodes;
   ln.probes += 2u * commits;
@@ -1612,6 +1679,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     const uint64_t tile = s_tile;
     PROF(0)
     if (tile >= n_tiles) break;
+    WCOUNT(0)
 #ifndef NIMBLE_STATIC_TILES
     if (tid == 0) fetch_tile(false);  // (consumed at the head of the next round)
 #endif
@@ -1722,8 +1790,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
           bool some;
           if (MODE == 1) {
             const uint32_t base0 = m ? mate1_at : 0u;
-            some = p.num_mismatches == 0 ? walk_fast<true>(ix, ln, base0, L[m], 0u, pre_state, pre_seed, cov, mis)
-                                         : walk_fast<false>(ix, ln, base0, L[m], p.num_mismatches, pre_state, pre_seed, cov, mis);
+            some = p.num_mismatches == 0 ? walk_fast<true>(ix, ln, base0, L[m], 0u, pre_state, pre_seed, cov, mis PROF_PASS)
+                                         : walk_fast<false>(ix, ln, base0, L[m], p.num_mismatches, pre_state, pre_seed, cov, mis PROF_PASS);
           } else {
             some = walk(ix, ln, m ? mate1_at : 0u, L[m], p.num_mismatches, cov, mis, pre_state, pre_seed PROF_PASS);
           }
@@ -1762,6 +1830,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
                   // claim / verify kernels
                   cls = CLS_PENDING;
                   if (MODE == 1) {
+                    WCOUNT(13)
                     ln.fbase = ix.srec_base[ln.last_rec];
                     finish_class<WIDE>(ix, ln, dhash, nullptr, mres);
                   }
@@ -1771,6 +1840,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
                     uint64_t pos = dhash & ix.intern_mask;
                     for (;;) {
                       const uint64_t slot = ix.intern[pos];
+                      WCOUNT(14)
                       if (slot == 0) break;
                       const uint32_t id = (uint32_t)slot;
                       if ((uint32_t)(slot >> 32) == tag && id != INTERN_PENDING && id < ix.cls_cap) {
@@ -1841,7 +1911,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
 #endif
     if (any_walk) c_seeded++;
   }
-#if NIMBLE_PROFILE_SECTIONS
+#if NIMBLE_PROFILE_SECTIONS == 1
   if ((tid & 63u) == 0)
     for (int i = 0; i < 10; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
 #endif

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -49,6 +50,58 @@ __global__ __launch_bounds__(256, 8) void k_chain(const uint4 *__restrict__ tab,
   if (t == 0x12345678u) out[0] = t;
 }
 
+// The same chain (2 loads of 16 bytes per step, 32 ops, one chain) with explicit cache-policy bits on the gathers:
+// does a policy that does not allocate the line in the CU's L1 raise the rate of distinct lines per CU?
+#define POLICY_KERNEL(NAME, BITS)                                                                                       \
+  __global__ __launch_bounds__(256, 8) void NAME(const uint4 *__restrict__ tab, uint32_t mask, uint32_t steps, uint32_t *out) { \
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;                                                           \
+    uint32_t idx = (g * 2654435761u) & mask, acc = g;                                                                   \
+    for (uint32_t s = 0; s < steps; ++s) {                                                                              \
+      uint4 r0, r1;                                                                                                     \
+      const uint4 *p = tab + (size_t)idx * 4;                                                                           \
+      asm volatile("global_load_dwordx4 %0, %2, off " BITS "\n\tglobal_load_dwordx4 %1, %2, off offset:16 " BITS      \
+                   "\n\ts_waitcnt vmcnt(0)"                                                                           \
+                   : "=&v"(r0), "=&v"(r1)                                                                               \
+                   : "v"(p)                                                                                             \
+                   : "memory");                                                                                         \
+      uint32_t x = r0.x ^ acc;                                                                                          \
+      x += r1.y;                                                                                                        \
+      _Pragma("unroll") for (int w = 0; w < 32; ++w) x = x * 1664525u + 1013904223u + (x >> 7);                         \
+      acc = x;                                                                                                          \
+      idx = (r0.w ^ (x & 0xFFu)) & mask;                                                                                \
+    }                                                                                                                   \
+    if (acc == 0x12345678u) out[0] = acc;                                                                               \
+  }
+POLICY_KERNEL(k_pol_none, "")
+POLICY_KERNEL(k_pol_nt, "nt")
+POLICY_KERNEL(k_pol_sc0, "sc0")
+POLICY_KERNEL(k_pol_sc1, "sc1")
+POLICY_KERNEL(k_pol_sc0sc1, "sc0 sc1")
+POLICY_KERNEL(k_pol_sc0nt, "sc0 nt")
+POLICY_KERNEL(k_pol_sc1nt, "sc1 nt")
+POLICY_KERNEL(k_pol_all, "sc0 sc1 nt")
+
+template <class K>
+static int run_policy(const char *what, K kern, const uint4 *tab, uint32_t records, uint32_t steps, uint32_t *out) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  float best = 1e9f;
+  const int grid = 2048;
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, tab, records - 1, steps, out);
+    CHECK(hipEventRecord(b, 0));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+  }
+  printf("policy %-12s table %7.1f MiB  %.3f ms  %.1f G lane-steps/s\n", what, records * 64.0 / (1 << 20), best,
+         (double)grid * 256 * steps / best / 1e6);
+  return 0;
+}
+
 template <int LOADS, int WORK, int CHAINS>
 static int run(const char *what, const uint4 *tab, uint32_t records, uint32_t steps, uint32_t *out, const uint4 *pollute, uint64_t pn) {
   hipEvent_t a, b;
@@ -86,6 +139,19 @@ int main() {
   CHECK(hipMalloc(&pollute, pn * 16));
   CHECK(hipMemset(pollute, 1, pn * 16));
   const uint32_t steps = 200;
+  if (getenv("CHAIN_POLICIES")) {
+    for (uint32_t rec : {1u << 15, 1u << 20}) {
+      run_policy("none", k_pol_none, tab, rec, steps, out);
+      run_policy("nt", k_pol_nt, tab, rec, steps, out);
+      run_policy("sc0", k_pol_sc0, tab, rec, steps, out);
+      run_policy("sc1", k_pol_sc1, tab, rec, steps, out);
+      run_policy("sc0 sc1", k_pol_sc0sc1, tab, rec, steps, out);
+      run_policy("sc0 nt", k_pol_sc0nt, tab, rec, steps, out);
+      run_policy("sc1 nt", k_pol_sc1nt, tab, rec, steps, out);
+      run_policy("sc0 sc1 nt", k_pol_all, tab, rec, steps, out);
+    }
+    return 0;
+  }
   for (uint32_t rec : {1u << 15, 1u << 17, 1u << 20, 1u << 24}) {  // 2 MiB, 8 MiB, 64 MiB, 1 GiB
     run<2, 4, 1>("2 loads, 32 ops, 1 chain", tab, rec, steps, out, nullptr, 0);
     run<4, 4, 1>("4 loads, 32 ops, 1 chain", tab, rec, steps, out, nullptr, 0);

@@ -17,7 +17,7 @@ names, seqs = synth.make_library(T)
 lib = nim.Library(text=json.dumps(synth.library_json(names, seqs)), strand_filter="unstranded").build_index(0)
 ctx = lib.device_context()
 SECT = ["tile fetch+barrier", "key load+probe", "partition", "walk misc", "seed phase", "walk loop", "class+thresholds",
-        "stores+tail", "-", "-"]
+        "stores+tail", "re-seed search", "-"]
 CASES = [
     ("bench recipe", None, 0.005),
     ("on-target, exact", (1.0, 1.0, 1.0, 1.0), 0.0),
@@ -39,6 +39,13 @@ for tag, mix, subst in CASES:
         t = ctx.timing()
     if nim.hip_lib().nimble_debug_sections(out, 1) != 1:
         raise SystemExit("this build has no section clocks")
-    tot = float(sum(out[i] for i in range(8))) or 1.0
-    print("%-32s k_align %.3f ms  " % (tag, t["align"]) + "  ".join("%s %.1f%%" % (SECT[i], 100.0 * out[i] / tot) for i in range(8)), flush=True)
+    if os.environ.get("SECTION_RAW"):   # a -DNIMBLE_PROFILE_SECTIONS=2 build: wave-level trip counts of the divergent blocks
+        names = ["tiles", "walk_fast calls", "walk iterations", "record loads", "mismatch blocks", "commits", "junctions",
+                 "find_match calls", "scan rounds", "filter-line blocks", "candidate probes", "re-seed searches",
+                 "left-extension steps", "class lookups", "intern probe steps", "-"]
+        print("%-32s k_align %.3f ms  " % (tag, t["align"]) + "  ".join("%s %d" % (names[i], out[i]) for i in range(15)), flush=True)
+        del reads
+        continue
+    tot = float(sum(out[i] for i in range(9))) or 1.0
+    print("%-32s k_align %.3f ms  " % (tag, t["align"]) + "  ".join("%s %.1f%%" % (SECT[i], 100.0 * out[i] / tot) for i in range(9)), flush=True)
     del reads
