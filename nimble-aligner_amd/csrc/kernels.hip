@@ -42,7 +42,7 @@ constexpr int PACK_BLOCK = 256;
 constexpr int ALIGN_BLOCK = NIMBLE_ALIGN_BLOCK;  // reads per tile (64 .. 512: the wave counters below hold 8 waves)
 constexpr int ALIGN_GRID = 2048 * 256 / ALIGN_BLOCK;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
 constexpr int LDS_COLS = 4;
-constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds
+constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds, lengths
 constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
 
 // NIMBLE_PROFILE_SECTIONS (debug builds only, tools/build_variant.sh prof -DNIMBLE_PROFILE_SECTIONS=1): wave clock cycles
@@ -1604,6 +1604,10 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
   uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
   uint16_t *s_perm = reinterpret_cast<uint16_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8);
+  // per read of the tile: aligned length of mate 0 | of mate 1 << 16 | length of mate 0 << 32 | prefilter verdicts << 48, 56 --
+  // loaded with the key in read order (whole lines) and picked up from here behind the partition: the lanes used to gather
+  // them again from the call's arrays for their permuted reads, two more round trips in every tile's chain
+  uint64_t *s_meta = reinterpret_cast<uint64_t *>(extra + 16 + 64 + ALIGN_BLOCK * 8 + ALIGN_BLOCK * 2);
   uint64_t prev_tile = ~0ULL;
   // Tiles are handed out dynamically (they differ a lot in cost), but NOT through one counter: atomics on one address run
   // at ~80 M/s on this chip whoever issues them, so an increment per 256-read tile is 39 k increments per 10 M reads =
@@ -1688,6 +1692,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     const uint64_t r_own = tile * ALIGN_BLOCK + tid;
     uint32_t kind = 2;  // 0 = needs a seed scan, 1 = seed known, 2 = nothing to walk for mate 0
     uint64_t seedv = ~0ULL;
+    uint64_t metav = 0;
     if (r_own < n) {
       // Everything the tile needs from memory is asked for at once: the key words do not wait for the lengths (what lies
       // behind a key is masked when the lengths are there).  A tile is a chain of dependent round trips -- tile index,
@@ -1697,6 +1702,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
       const uint32_t k0 = rd_len(cb, 0, r_own);
       const uint32_t l1 = nm == 2 ? rd_len(cb, 1, r_own) : 0u;
       const uint32_t l0 = rd_alen(cb, 0, r_own);  // bases of mate 0 that are aligned
+      metav = (uint64_t)l0 | ((uint64_t)k0 << 32) | ((uint64_t)pre0 << 48);
+      if (nm == 2) metav |= ((uint64_t)rd_alen(cb, 1, r_own) << 16) | ((uint64_t)rd_pre(cb, 1, r_own) << 56);
       constexpr uint32_t KCH = 8;
       const uint64_t *row = cb.rec ? cb.rec + r_own * cb.rec_words : nullptr;
       for (uint32_t w0 = 0; w0 < kw; w0 += KCH) {
@@ -1729,6 +1736,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     // that the waves of the block are (nearly) homogeneous and most of them skip the scan rounds entirely
     PROF(1)
     s_seed[tid] = seedv;
+    s_meta[tid] = metav;
     {
       const uint64_t b0 = __ballot(kind == 0), b1 = __ballot(kind == 1);
       const uint32_t wv = tid >> 6, lane = tid & 63u;
@@ -1761,11 +1769,12 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     const uint64_t pre_seed = s_seed[slot];
     uint32_t L[2] = {0, 0};   // aligned bases per mate
     uint32_t mate1_at = 0;    // where mate 1 starts inside the key (the untrimmed length of mate 0)
+    const uint64_t meta = s_meta[slot];
     if (active) {
-      L[0] = rd_alen(cb, 0, r);
+      L[0] = (uint32_t)meta & 0xFFFFu;
       if (nm == 2) {
-        L[1] = rd_alen(cb, 1, r);
-        mate1_at = rd_len(cb, 0, r);
+        L[1] = (uint32_t)(meta >> 16) & 0xFFFFu;
+        mate1_at = (uint32_t)(meta >> 32) & 0xFFFFu;
       }
     }
     bool any_walk = false;
@@ -1779,7 +1788,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
       mres.base = 0;
       mres.mask = 0;
       if (active) {
-        uint32_t pre = rd_pre(cb, m, r);
+        const uint32_t pre = (uint32_t)(meta >> (48 + 8 * m)) & 0xFFu;
         if (pre != R_TODO) {
           reason = pre;
           if (m == 0) c_pre++;
