@@ -1092,7 +1092,7 @@ static int setup_call(nimble_ctx *c, const nimble_align_params *p, uint64_t n, b
   // the walk keeps every key of a tile in LDS; one workgroup may take up to 160 KiB on gfx950
   // (an index with wide allele families adds its per-lane row window: DevIndex.window_words words of every lane)
   const size_t window_bytes = c->ix->dev.all_local ? 0 : (size_t)c->ix->dev.window_words * 256 * 8;
-  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 5120 + window_bytes > 160 * 1024)
+  if ((size_t)(kw + 1) * 256 * 8 + (size_t)align_lds_cols() * 256 * 4 + 4096 + window_bytes > 160 * 1024)
     return fail(NIMBLE_E_INVALID, window_bytes ? "nimble_call: reads too long for the LDS-resident walk beside this index's row "
                                                  "window (set NIMBLE_LDS_WINDOW_WORDS lower, or NIMBLE_LDS_WINDOW=0)"
                                                : "nimble_call: reads too long for the LDS-resident walk (max_len * mates > ~2400)");

@@ -42,7 +42,8 @@ constexpr int PACK_BLOCK = 256;
 constexpr int ALIGN_BLOCK = NIMBLE_ALIGN_BLOCK;  // reads per tile (64 .. 512: the wave counters below hold 8 waves)
 constexpr int ALIGN_GRID = 2048 * 256 / ALIGN_BLOCK;  // 256 CUs x 8 resident blocks; grid-stride over tiles of 256 reads
 constexpr int LDS_COLS = 4;
-constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds, lengths
+constexpr int ALIGN_LDS_EXTRA = 16 + 64 + ALIGN_BLOCK * 2 + ALIGN_BLOCK * 8;  // tile slot, wave counts, perm, seeds
+constexpr int ALIGN_LDS_META = ALIGN_BLOCK * 8;  // (fast walk only, behind them: lengths and verdicts per read of the tile)
 constexpr double MIN_ENTROPY_SCORE = 1.75;  // src/align.rs:19
 
 // NIMBLE_PROFILE_SECTIONS (debug builds only, tools/build_variant.sh prof -DNIMBLE_PROFILE_SECTIONS=1): wave clock cycles
@@ -1566,6 +1567,8 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
   // rows of the LDS columns: the key words, a zero word behind them -- and at least nm + 1, because a finished tile
   // leaves its results in the columns (below)
   const uint32_t krows = kw + 1u > (uint32_t)nm + 1u ? kw + 1u : (uint32_t)nm + 1u;
+  // (the LDS columns of the visited-colour lists: the fast walk keeps no lists -- 4 KiB less per block, an eighth block per CU)
+  constexpr int LIST_COLS = MODE == 1 ? 0 : LDS_COLS;
   Lane ln;
   ln.rd = col;
   ln.lc = reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) + tid;
@@ -1589,7 +1592,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
   ln.wacc[0] = ln.wacc[1] = ln.wacc[2] = ln.wacc[3] = 0;
   ln.wcap = WIDE ? ix.window_words : 0u;
   ln.wn = 0;
-  ln.wl = ln.wcap ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) + LDS_COLS * ALIGN_BLOCK) + ALIGN_LDS_EXTRA) + tid
+  ln.wl = ln.wcap ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) + LIST_COLS * ALIGN_BLOCK) + ALIGN_LDS_EXTRA) + tid
                   : nullptr;
   ln.cls_bits = ix.cls_bits;
   uint32_t c_seeded = 0, c_pre = 0;
@@ -1599,7 +1602,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
 
   // small block-shared arrays behind the columns in the dynamic region (extern base stays 16-byte aligned)
   uint8_t *extra = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(lds64 + (size_t)krows * ALIGN_BLOCK) +
-                                               LDS_COLS * ALIGN_BLOCK);
+                                               LIST_COLS * ALIGN_BLOCK);
   unsigned long long &s_tile = *reinterpret_cast<unsigned long long *>(extra);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(extra + 16);
   uint64_t *s_seed = reinterpret_cast<uint64_t *>(extra + 16 + 64);
@@ -1736,7 +1739,7 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     // that the waves of the block are (nearly) homogeneous and most of them skip the scan rounds entirely
     PROF(1)
     s_seed[tid] = seedv;
-    s_meta[tid] = metav;
+    if (MODE == 1) s_meta[tid] = metav;
     {
       const uint64_t b0 = __ballot(kind == 0), b1 = __ballot(kind == 1);
       const uint32_t wv = tid >> 6, lane = tid & 63u;
@@ -1769,7 +1772,15 @@ __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WA
     const uint64_t pre_seed = s_seed[slot];
     uint32_t L[2] = {0, 0};   // aligned bases per mate
     uint32_t mate1_at = 0;    // where mate 1 starts inside the key (the untrimmed length of mate 0)
-    const uint64_t meta = s_meta[slot];
+    // (the general walk's launch has no room for this array in LDS at the longest reads it takes: it asks the call's arrays)
+    uint64_t meta = 0;
+    if (MODE == 1) {
+      meta = s_meta[slot];
+    } else if (active) {
+      meta = (uint64_t)rd_alen(cb, 0, r) | ((uint64_t)rd_pre(cb, 0, r) << 48);
+      if (nm == 2)
+        meta |= ((uint64_t)rd_alen(cb, 1, r) << 16) | ((uint64_t)rd_len(cb, 0, r) << 32) | ((uint64_t)rd_pre(cb, 1, r) << 56);
+    }
     if (active) {
       L[0] = (uint32_t)meta & 0xFFFFu;
       if (nm == 2) {
@@ -2698,12 +2709,12 @@ static void launch_align_kernel(hipStream_t s, const void *fn, size_t lds, const
   (void)hipLaunchKernel(fn, dim3((uint32_t)grid), dim3(ALIGN_BLOCK), args, lds, s);
 }
 
-static size_t align_lds(const DevIndex &ix, const CallBuffers &cb) {
+static size_t align_lds(const DevIndex &ix, const CallBuffers &cb, bool fast) {
   const bool wide = ix.all_local == 0;
   const uint32_t nm = cb.paired ? 2u : 1u;
   const uint32_t min_rows = nm + 1u;  // a finished tile leaves its results in the columns
   const uint32_t krows = cb.key_words + 1 > min_rows ? cb.key_words + 1 : min_rows;
-  return (size_t)krows * ALIGN_BLOCK * 8 + (size_t)LDS_COLS * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA +
+  return (size_t)krows * ALIGN_BLOCK * 8 + (size_t)(fast ? 0 : LDS_COLS) * ALIGN_BLOCK * 4 + ALIGN_LDS_EXTRA + (fast ? ALIGN_LDS_META : 0) +
          (wide ? (size_t)ix.window_words * ALIGN_BLOCK * 8 : 0);  // (the LDS row window of wide indexes, push_col)
 }
 
@@ -2717,7 +2728,7 @@ void launch_align(hipStream_t s, const DevIndex &ix, const nimble_align_params &
   static const bool fast_on = !(getenv("NIMBLE_FAST_ALIGN") && atoi(getenv("NIMBLE_FAST_ALIGN")) == 0);
   const bool fast = fast_on && !wide && ix.srec && ix.mleft;
   (void)hipMemsetAsync(cb.tile_ctr, 0, (size_t)TILE_COUNTERS * TILE_COUNTER_STRIDE, s);  // (the launch's tile counters)
-  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, fast ? 1 : 0), align_lds(ix, cb), ix, p, cb, tiles,
+  launch_align_kernel(s, align_kernel(cb.paired != 0, want_counters != 0, wide, fast ? 1 : 0), align_lds(ix, cb, fast), ix, p, cb, tiles,
                       grid_pct, n_cus, 0);
 }
 
