@@ -1202,12 +1202,20 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
       const uint32_t hdr = r0.x, nb = hdr & 63u;
       if (tneed == 0) {
         WCOUNT(5)
-        // all 32 bases behind the substitution agree: the reference's seed is the k-mer that ends with the last of them,
-        // in this unitig -- entered the way a seed is entered (two probes: p missed, p + 3 hit; the 30 bases of the seed
-        // count, the 32 compared did not)
+        tneed = NO_TENT;
+        // the flank test of the short cut (walk(): "on"), asked only now that the 32 bases behind the substitution have agreed
+        // -- a stretch that breaks off earlier never needed it, and a positive answer falls back exactly as a broken stretch
+        // does (same position, same coverage, same counters)
+        if (mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + t_pos + 1u, KMER - 1u))) {
+          cov = t_pos - (kpos - cov - 1u);
+          kpos = t_pos;
+          status = 2;
+          continue;
+        }
+        // the reference's seed is the k-mer that ends with the last of the 32 bases, in this unitig -- entered the way a seed
+        // is entered (two probes: p missed, p + 3 hit; the 30 bases of the seed count, the 32 compared did not)
         cov -= 2;
         ++commits;
-        tneed = NO_TENT;
         push = true;
       }
       bool entered = false;
@@ -1247,9 +1255,8 @@ __device__ __forceinline__ bool walk_fast(const DevIndex &ix, Lane &ln, uint32_t
               kpos = t_pos;
               adv = 0;
               status = 2;
-            } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos &&
-                       !mleft_maybe(ix.mleft, ix.mleft_log2, lds_bits(rd, base0 + kpos + k + 1u, KMER - 1u))) {
-              // the rest of this very stretch agrees: go on tentatively from here (walk(): "on")
+            } else if (cnt == 1u && kpos + k + 3u <= last_kmer_pos) {
+              // the rest of this very stretch agrees: go on tentatively from here (walk(): "on"; its flank test: at the commit)
               t_pos = kpos + k;  // (where the walk stands if the short cut does not work out: at the differing base)
               mm += 1;
               cov -= 1;  // (the differing base itself is not covered)
