@@ -1555,13 +1555,17 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
 // (residency: 8 waves per SIMD for the general walk -- 7 and 6 measured slower, round 2 --, 6 for indexes with wide classes (the
 // register window), 7 for the fast walk: at 64 registers it spills inside the tile loop, 72 hold it: bench recipe 1.149 -> 1.115 ms,
-// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; paired calls carry two mates' state: 6 waves, configs[3] 2.57 -> 2.50 ms;
+// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; paired calls carry two mates' state: 5 waves (102 registers, no scratch:
+// configs[3] 2.37 ms at 7 waves, 2.26 at 6, 2.19 at 5 and at 4);
 // the counters variant of the fast walk, never timed, gets half of that:
 // profiles/r04_experiments.txt 8)
 #ifndef NIMBLE_FAST_WAVES
 #define NIMBLE_FAST_WAVES 7
 #endif
-__global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : (PAIRED ? NIMBLE_FAST_WAVES - 1 : NIMBLE_FAST_WAVES))
+#ifndef NIMBLE_FAST_WAVES_PAIRED
+#define NIMBLE_FAST_WAVES_PAIRED (NIMBLE_FAST_WAVES - 2)
+#endif
+__global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : (PAIRED ? NIMBLE_FAST_WAVES_PAIRED : NIMBLE_FAST_WAVES))
                                                     : (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES)) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   static_assert(!(WIDE && MODE == 1), "the fast walk is for indexes whose classes all have the mask form");
