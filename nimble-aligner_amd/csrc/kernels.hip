@@ -1562,11 +1562,14 @@ template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
 #ifndef NIMBLE_FAST_WAVES
 #define NIMBLE_FAST_WAVES 7
 #endif
+#ifndef NIMBLE_WIDE_WAVES
+#define NIMBLE_WIDE_WAVES ((NIMBLE_ALIGN_WAVES * 3) / 4)
+#endif
 #ifndef NIMBLE_FAST_WAVES_PAIRED
 #define NIMBLE_FAST_WAVES_PAIRED (NIMBLE_FAST_WAVES - 2)
 #endif
 __global__ __launch_bounds__(ALIGN_BLOCK, MODE == 1 ? (COUNTERS ? NIMBLE_FAST_WAVES / 2 : (PAIRED ? NIMBLE_FAST_WAVES_PAIRED : NIMBLE_FAST_WAVES))
-                                                    : (WIDE ? (NIMBLE_ALIGN_WAVES * 3) / 4 : NIMBLE_ALIGN_WAVES)) void k_align(DevIndex ix, nimble_align_params p,
+                                                    : (WIDE ? NIMBLE_WIDE_WAVES : NIMBLE_ALIGN_WAVES)) void k_align(DevIndex ix, nimble_align_params p,
                                                                            CallBuffers cb) {
   static_assert(!(WIDE && MODE == 1), "the fast walk is for indexes whose classes all have the mask form");
   constexpr int want_counters = COUNTERS ? 1 : 0;
