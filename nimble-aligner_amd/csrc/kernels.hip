@@ -1103,14 +1103,14 @@ __device__ bool walk(const DevIndex &ix, Lane &ln, uint32_t base0, uint32_t L, u
 // case in every iteration.  This one walks the index's STRETCH RECORDS (flat_index.h: a unitig's bases behind its first
 // k-mer cut into stretches of at most 32, a 32-byte record each): one step = one record (two 16-byte gathers of one line)
 // = one compare = one way out -- the next stretch of the same unitig, or the unitig behind the read's next base.  What
-// bounds both walks is the rate at which a CU gathers DISTINCT LINES (tools/probes/chain.hip: 213 G lane-gathers a second
-// chip-wide from an L2-resident table whatever the number of chains in flight per lane, 160 G with four loads per line,
-// 58 G from beyond L2), so what counts is gathers per read.  The seed search is walk()'s (find_match); a substitution is
+// bounds both walks is VALU issue at a quarter of the lanes -- how often a wave runs a block for a few of its lanes -- and the
+// length of a tile's chain of round trips (profiles/r04_experiments.txt 13; the chip's rate of dependent gathers, item 1 there,
+// is three times what the launch asks of it).  The seed search is walk()'s (find_match); a substitution is
 // stepped over the way walk() does it (the local re-seed: the 32 bases behind it must agree along the graph, then the
 // reference's next seed is the k-mer that ends there), a read that leaves the graph searches its next seed and walks on.
 // Everything else is walk()'s, step by step: the left extension behind a late first seed (over the general walk's unitig
-// records: once per read, for one bench read in seventy), the flank test where a substitution is met, the mismatch budget
-// per unitig.  (A first form handed those reads to a second launch of the general walk through a redo list: 2.4 % of the
+// records: once per read, for one bench read in seventy), the flank test of a short cut (asked when it commits), the mismatch
+// budget per unitig.  (A first form handed those reads to a second launch of the general walk through a redo list: 2.4 % of the
 // bench reads, 0.14 ms per 10 M -- the latency of that launch's hardest tile; profiles/r04_experiments.txt 3, 10.)
 // Same counters as walk(): a unitig entered or re-entered by a seed counts as a visit, a committed short cut as two probes.
 // STRICT: num_mismatches == 0 (the usual setting); otherwise a unitig tolerates `allowed` differing bases.
