@@ -235,6 +235,16 @@ def main():
             port = so.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (counting the devices does not initialise the GPU; a node with fewer devices than ranks gets one line that says so
+        # instead of N tracebacks)
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = -1
+        if 0 <= have < args.gpus:
+            print(json.dumps({"error": "bench.py --gpus %d: this node shows %d device(s)" % (args.gpus, have), "n_gpus": args.gpus}))
+            raise SystemExit(2)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
