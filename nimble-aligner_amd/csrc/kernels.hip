@@ -1555,7 +1555,7 @@ __device__ __forceinline__ bool window_equals_class(const DevIndex &ix, const La
 template <bool PAIRED, bool COUNTERS, bool WIDE, int MODE>
 // (residency: 8 waves per SIMD for the general walk -- 7 and 6 measured slower, round 2 --, 6 for indexes with wide classes (the
 // register window), 7 for the fast walk: at 64 registers it spills inside the tile loop, 72 hold it: bench recipe 1.149 -> 1.115 ms,
-// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; paired calls carry two mates' state: 5 waves (102 registers, no scratch:
+// exact reads 0.891 -> 0.771, 6 waves 1.207 / 0.761; paired calls carry two mates' state: 5 waves (92 registers, 48 B of scratch:
 // configs[3] 2.37 ms at 7 waves, 2.26 at 6, 2.19 at 5 and at 4);
 // the counters variant of the fast walk, never timed, gets half of that:
 // profiles/r04_experiments.txt 8)
