@@ -308,10 +308,19 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
   }
   });
   timer.lap("edges");
-  // 6. dictionary, load factor <= 0.5
+  // 6. dictionary, load factor <= 0.25 (before rounding the table up to a power of two).  A wave probes for 64 reads at once and
+  // waits for its worst lane: at load 0.31 (the bench library in a table sized for 0.5) the probes of a wave of bench reads went
+  // 6.5 times to a second, third ... slot, each a round trip beyond L2 for one or two lanes; at 0.15: k_align -3.4 % on the bench
+  // reads, -5.5 % on foreign reads; twice that table again (256 MiB, past the Infinity Cache) gives half of it back
+  // (profiles/r04_experiments.txt 26)
   uint64_t slots = 64;
   uint32_t log2_slots = 6;
-  while (slots < 2 * (uint64_t)n + 2) { slots <<= 1; ++log2_slots; }
+  static const uint64_t per_kmer = [] {
+    const char *e = getenv("NIMBLE_HT_SLOTS_PER_KMER");  // (experiments: dictionary slots per k-mer, before rounding up to 2^k)
+    const long v = e ? atol(e) : 4;
+    return (uint64_t)(v >= 2 && v <= 64 ? v : 4);
+  }();
+  while (slots < per_kmer * (uint64_t)n + 2) { slots <<= 1; ++log2_slots; }
   if (log2_slots + 2 > 32) throw std::runtime_error("index build: too many k-mers for the 32-bit slot hash");
   out.ht_slots = slots;
   out.ht_log2 = log2_slots;
@@ -324,10 +333,17 @@ void build_flat_index(const uint8_t *seqs, const uint64_t *off, uint32_t n_seqs,
     out.ht[2 * h + 1] = ((uint64_t)kmer_node[i] << 32) | kmer_off[i];
   }
   timer.lap("dictionary");
-  // presence filter: 2 bits in each of 7 lines per k-mer, sized for <= ~16 % bit density, i.e. a false
-  // positive rate of ~2.5 % per position (the 24 shared bits allow up to 2^24 lines)
+  // presence filter: 2 bits in each of 7 lines per k-mer, sized for <= ~8 % bit density (the 24 shared bits allow up to 2^24
+  // lines).  A false positive costs its wave a dictionary probe for ONE lane (a hash, a fetch from beyond L2): at 16 % density a
+  // wave of foreign reads ran 1.5 such probes per filter round; 8 %: k_align -1.5 % on the bench reads, -2.6 % on foreign reads;
+  // 4 %: another half per cent (profiles/r04_experiments.txt 25)
+  static const double density = [] {
+    const char *e = getenv("NIMBLE_FILTER_DENSITY");  // (experiments: bit density the filter is sized for)
+    const double d = e ? atof(e) : 0.08;
+    return d > 0.001 && d < 0.9 ? d : 0.08;
+  }();
   out.bm_lines_log2 = 8;
-  while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND * 2.0 > 0.16 * 128.0 * (double)(1ull << out.bm_lines_log2))
+  while (out.bm_lines_log2 < 24 && (double)n * SCAN_ROUND * 2.0 > density * 128.0 * (double)(1ull << out.bm_lines_log2))
     ++out.bm_lines_log2;
   out.bitmap.assign((size_t)4 << out.bm_lines_log2, 0);
   // first level in front of it: one bit per possible value of the 12 shared bases (4^12 bits = 2 MiB, small enough to

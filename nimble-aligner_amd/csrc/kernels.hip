@@ -557,6 +557,7 @@ __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t b) {
 __device__ __noinline__ uint64_t ht_resolve_slow(const uint4 *__restrict__ ht, uint64_t mask, uint64_t km,
                                                  uint64_t h) {
   for (;;) {
+    WCOUNT(15)
     h = (h + 1) & mask;
     uint4 s = ht[h];
     uint64_t key = u64of(s.x, s.y);

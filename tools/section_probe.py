@@ -42,8 +42,8 @@ for tag, mix, subst in CASES:
     if os.environ.get("SECTION_RAW"):   # a -DNIMBLE_PROFILE_SECTIONS=2 build: wave-level trip counts of the divergent blocks
         names = ["tiles", "walk_fast calls", "walk iterations", "record loads", "mismatch blocks", "commits", "junctions",
                  "find_match calls", "scan rounds", "filter-line blocks", "candidate probes", "re-seed searches",
-                 "left-extension steps", "class lookups", "intern probe steps", "-"]
-        print("%-32s k_align %.3f ms  " % (tag, t["align"]) + "  ".join("%s %d" % (names[i], out[i]) for i in range(15)), flush=True)
+                 "left-extension steps", "class lookups", "intern probe steps", "dictionary second probes"]
+        print("%-32s k_align %.3f ms  " % (tag, t["align"]) + "  ".join("%s %d" % (names[i], out[i]) for i in range(16)), flush=True)
         del reads
         continue
     tot = float(sum(out[i] for i in range(9))) or 1.0
